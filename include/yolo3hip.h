@@ -1,0 +1,197 @@
+/*
+ * yolo3hip.h -- C ABI of libyolo3hip.so, the MI355X (gfx950) hot path of the
+ * YOLOv3 train / inference pipeline of usnistgov/object-detection-yolov3.
+ *
+ * The reference has no FFI of its own: its hot path is TensorFlow ops called
+ * from Python (model.py) plus NumPy post-processing (bbox_utils.py).  Each
+ * entry point below names the reference call site (file:line under the
+ * reference checkout) whose arithmetic it replaces.  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is DEVICE memory unless it says host
+ *   - activations are NHWC fp32 with an explicit row pitch `ld` (floats per
+ *     pixel, >= channels) so producers can write straight into concat buffers
+ *   - conv kernels are Keras layout [kh][kw][Cin][Cout] (= [tap][Cin][Cout])
+ *   - all work is enqueued on `stream` (a hipStream_t) and returns at once
+ *   - return 0 on success, negative Y3_E* on error; y3_last_error() = message
+ *   - no entry point allocates, frees or synchronises (graph-capture safe)
+ */
+#ifndef YOLO3HIP_H
+#define YOLO3HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Y3_OK 0
+#define Y3_EINVAL (-1)   /* bad argument / unsupported shape */
+#define Y3_ELAUNCH (-2)  /* HIP launch error */
+
+typedef void* y3_stream_t; /* hipStream_t */
+
+const char* y3_last_error(void);
+int y3_version(void);
+
+/* ---- epilogue flags of y3_conv2d_fwd / y3_conv2d_dgrad ------------------ */
+#define Y3_EPI_LRELU 1u  /* v = v > 0 ? v : alpha*v   (tf.nn.leaky_relu, model.py:34) */
+#define Y3_EPI_ACCUM 2u  /* dst += v instead of dst = v */
+
+/*
+ * Tensor view: NHWC, `ld` floats between consecutive pixels.
+ */
+typedef struct y3_tensor {
+    float* ptr;
+    int n, h, w, c;
+    int ld;
+} y3_tensor;
+
+/*
+ * conv_layer forward (model.py:29-39 Conv2D part, :108-120 detection_layer).
+ *   dst = epi( conv_SAME(src, wt) + bias )
+ * epi: optional leaky-relu, then optional per-channel affine v*scale+shift
+ * (inference-mode BatchNorm folded), then optional residual add (model.py:47).
+ * If `stats` != NULL the kernel also writes per-row-tile partial sums of the
+ * post-activation value: stats[tile][0][c] = sum, stats[tile][1][c] = sum of
+ * squares (training-mode BatchNorm statistics, model.py:38); the number of
+ * tiles is y3_conv2d_stats_tiles().
+ * TF 'same' padding (pad_before = pad_total/2, extra at the end).
+ */
+int y3_conv2d_fwd(const y3_tensor* src, const float* wt, const float* bias, int ksize, int stride,
+                  const y3_tensor* dst, unsigned flags, float alpha,
+                  const float* scale, const float* shift, const y3_tensor* resid,
+                  float* stats, y3_stream_t stream);
+int y3_conv2d_stats_tiles(int m, int cout);
+
+/*
+ * Gradient w.r.t. the conv input (tape.gradient, model.py:496):
+ *   dsrc (+)= conv_transpose(ddst, wt)
+ * wt_t is the kernel with the two channel axes swapped: [tap][Cout][Cin]
+ * (y3_transpose_weights).  ddst is the gradient at the conv output (dst of
+ * the forward), dsrc has the forward's src geometry.
+ */
+int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksize, int stride,
+                    const y3_tensor* dsrc, unsigned flags, y3_stream_t stream);
+
+/*
+ * Gradient w.r.t. the kernel:  dw[tap][ci][co] = sum_pixels src*ddst.
+ * workspace: y3_conv2d_wgrad_workspace() bytes (split-K partial slabs).
+ */
+int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride,
+                    float* dw, void* workspace, size_t workspace_bytes, y3_stream_t stream);
+size_t y3_conv2d_wgrad_workspace(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride);
+
+/* wt_t[tap][co][ci] = wt[tap][ci][co] */
+int y3_transpose_weights(const float* wt, float* wt_t, int taps, int cin, int cout, y3_stream_t stream);
+
+/* ---- BatchNormalization(axis=1), eps 1e-3, momentum .99 (model.py:38) ---- */
+/*
+ * Training forward, step 1: reduce conv-epilogue partials to batch mean and
+ * biased variance; write scale = gamma*rsqrt(var+eps), shift = beta-mean*scale;
+ * save mean / rstd for backward; update moving stats
+ * (moving = moving*mom + batch*(1-mom), variance Bessel-corrected).
+ */
+int y3_bn_stats_finalize(const float* stats, int tiles, int c, int count,
+                         const float* gamma, const float* beta, float eps, float momentum,
+                         float* moving_mean, float* moving_var,
+                         float* save_mean, float* save_rstd, float* scale, float* shift,
+                         y3_stream_t stream);
+/* moving-stats (inference) affine: scale = gamma*rsqrt(var+eps), shift = beta-mean*scale */
+int y3_bn_fold_inference(const float* gamma, const float* beta, const float* moving_mean,
+                         const float* moving_var, float eps, int c, float* scale, float* shift,
+                         y3_stream_t stream);
+/* y = a*scale + shift (+ resid)   (BN apply and the residual add of model.py:47) */
+int y3_bn_apply(const y3_tensor* a, const float* scale, const float* shift, const y3_tensor* resid,
+                const y3_tensor* y, y3_stream_t stream);
+/*
+ * Backward of conv_layer's tail  y = BN(lrelu(z)):  given dy and a = lrelu(z)
+ *   step 1 (reduce):   per-channel partial sums -> workspace
+ *   step 2 (finalize): dgamma, dbeta, dbias (bias gradient of the conv) and
+ *                      the per-channel coefficients k1,k2,k3 (coef[3][c])
+ *   step 3 (apply):    dz = (k1*dy + k2*a + k3) * (a > 0 ? 1 : alpha)
+ */
+int y3_bn_bwd_reduce(const y3_tensor* dy, const y3_tensor* a, const float* save_mean,
+                     const float* save_rstd, float alpha, float* partials, int* nparts,
+                     y3_stream_t stream);
+int y3_bn_bwd_partials(int m, int c); /* number of partial rows the reduce writes */
+int y3_bn_bwd_finalize(const float* partials, int nparts, int c, int count, const float* gamma,
+                       const float* save_mean, const float* save_rstd, float alpha,
+                       float* dgamma, float* dbeta, float* dbias, float* coef, y3_stream_t stream);
+int y3_bn_bwd_apply(const y3_tensor* dy, const y3_tensor* a, const float* coef, float alpha,
+                    const y3_tensor* dz, y3_stream_t stream);
+
+/* ---- upsample_2x: frozen all-ones Conv2DTranspose k2 s2 (model.py:94-105) ---- */
+/* out[n,2i+a,2j+b,co] = sum_ci in[n,i,j,ci] for every co */
+int y3_upsample_sum2x_fwd(const y3_tensor* in, const y3_tensor* out, y3_stream_t stream);
+/* din[n,i,j,ci] = sum_{a,b,co} dout[n,2i+a,2j+b,co] for every ci */
+int y3_upsample_sum2x_bwd(const y3_tensor* dout, const y3_tensor* din, y3_stream_t stream);
+
+/* ---- small data movement -------------------------------------------------- */
+int y3_copy(const y3_tensor* src, const y3_tensor* dst, y3_stream_t stream);        /* strided copy (tf.concat, model.py:368,375) */
+int y3_add_inplace(const y3_tensor* src, const y3_tensor* dst, y3_stream_t stream); /* dst += src (gradient fan-in) */
+int y3_fill(float* ptr, size_t count, float value, y3_stream_t stream);
+/* model input [N,C,H,W] -> NHWC with channels zero-padded to dst->c (multiple of 4) */
+int y3_nchw_to_nhwc(const float* src, int n, int c, int h, int w, const y3_tensor* dst, y3_stream_t stream);
+/* NHWC view -> dense [N,C,H,W] (feature-map export, model.py:462) */
+int y3_nhwc_to_nchw(const y3_tensor* src, float* dst, y3_stream_t stream);
+/* column sums: out[c] = sum_pixels src  (bias gradient of the detection layers) */
+int y3_colsum(const y3_tensor* src, float* out, y3_stream_t stream);
+
+/* ---- anchor decode: reorg_layer + convert_feature_map_to_inference_detections
+ *      (model.py:122-212).  fm[s]: NHWC [N,G,G,A*(5+K)]; out: [N,Nb,5+K] rows
+ *      [x0,y0,x1,y1,obj,cls..], scales coarse->fine, then row, col, anchor.
+ *      anchors: host [A][2] (w,h).  stride quirk Q6 reproduced:
+ *      x uses img_h/grid_h, y uses img_w/grid_w. */
+int y3_decode_fwd(const y3_tensor* fm, int nscales, const float* anchors_host, int num_anchors,
+                  int num_classes, int img_h, int img_w, float* out, y3_stream_t stream);
+
+/* ---- loss_layer forward + backward for one scale (model.py:230-354) --------
+ * fm NHWC [N,G,G,A*(5+K)], gt dense [N,G,G,A,5+K].  Adds the four terms
+ * (xy, wh, obj, class; each / local batch) into loss4[0..3] and writes
+ * dfm = d(total/global_batch)/d(fm) with fm's layout.  loss4 is accumulated
+ * (zero it before the first scale).  workspace: y3_loss_workspace_bytes().
+ */
+int y3_loss_fwd_bwd(const y3_tensor* fm, const float* gt, const float* anchors_host, int num_anchors,
+                    int num_classes, int img_h, int img_w, float global_batch,
+                    float* loss4, const y3_tensor* dfm, void* workspace, y3_stream_t stream);
+size_t y3_loss_workspace_bytes(void);
+
+/* ---- tf.keras.optimizers.Adam.apply_gradients (model.py:451,500) ----------
+ * m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= lr_t*m/(sqrt(v)+eps), with
+ * lr_t read from DEVICE memory (*lr_t_dev) so the launch is graph-replayable. */
+int y3_adam_step(float* param, const float* grad, float* m, float* v, size_t count,
+                 const float* lr_t_dev, float beta1, float beta2, float eps, y3_stream_t stream);
+
+/* ---- class-wise NMS (bbox_utils.py:200-281; inference.py:72-79) ------------
+ * rows [N,Nb,5+K].  A row is a candidate of class c if w > min_box and
+ * h > min_box (strict) and sqrt(cls_c*obj) >= score_thr; greedy suppression
+ * keeps iou <= iou_thr, in descending score order (ties: higher row index
+ * first).  Optional clip of the corners to [0,clip_w]x[0,clip_h] before
+ * everything (inference.py:62-65 intent); pass clip_w <= 0 to disable.
+ * keep_idx [N,K,max_keep] int32 row indices in selection order,
+ * keep_cnt [N,K] int32, keep_score [N,K,max_keep] fp32.
+ * workspace: y3_nms_workspace_bytes(). */
+int y3_nms_per_class(const float* rows, int n, int nb, int num_classes, float min_box,
+                     float score_thr, float iou_thr, float clip_w, float clip_h,
+                     int* keep_idx, int* keep_cnt, float* keep_score, int max_keep,
+                     void* workspace, size_t workspace_bytes, y3_stream_t stream);
+size_t y3_nms_workspace_bytes(int n, int nb, int num_classes);
+/* bbox_utils.single_class_nms (bbox_utils.py:217-237): rows5 [M,5] = x0,y0,x1,y1,score; every row is
+ * a candidate, the score is used as is.  keep_idx/keep_score [M], keep_cnt [1].
+ * workspace: y3_nms_workspace_bytes(1, M, 1). */
+int y3_nms_single_class(const float* rows5, int m, float iou_thr, int* keep_idx, int* keep_cnt,
+                        float* keep_score, void* workspace, size_t workspace_bytes, y3_stream_t stream);
+
+/* ---- imagereader.zscore_normalize (imagereader.py:34-46) -------------------
+ * per image: mu = mean, sd = population std over all `count` values;
+ * out = sd <= 1 ? x-mu : (x-mu)/sd.  workspace: y3_zscore_workspace_bytes(n). */
+int y3_zscore(const float* in, float* out, int n, size_t count, void* workspace, y3_stream_t stream);
+size_t y3_zscore_workspace_bytes(int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO3HIP_H */

@@ -1,0 +1,751 @@
+// Implicit-GEMM convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32:
+// f32 in, f32 accumulate, bit-exact fmaf chain) for gfx950.
+//
+// One gather-GEMM kernel serves conv forward (model.py:29-39,108-120), the data
+// gradient (tape.gradient, model.py:496; stride-2 layers as 4 output-parity
+// launches so no MFMA work is wasted on structural zeros) and 1x1 convs:
+//     dst[pix(m)][n] = epi( sum_{t<taps} sum_{c<C} src[pix(m)+off(t)][c] * wt[wsel(t)][c][n] )
+// and a second kernel computes the kernel gradient
+//     dw[t][c][n]    = sum_m src[pix(m)+off(t)][c] * ddst[m][n]        (split over m)
+//
+// Data layout: activations NHWC (channel-contiguous) so the GEMM K axis (tap, c)
+// is contiguous per pixel; weights [tap][C][Nout] (Keras order) so a B row is
+// Nout-contiguous.  Tiles are staged global -> registers -> LDS (double buffered,
+// one barrier per K step); operands are read from LDS as
+//   A: one ds_read_b128 per lane = 4 consecutive k of its pixel row (rows padded
+//      to BK+4 floats: conflict-free), feeding 4 MFMAs
+//   B: ds_read_b32, 32 consecutive n per half-wave (conflict-free)
+// The k order inside a K step is permuted identically for A and B
+// (lane half h takes k = 8*kk + 4*h + i), which only reorders the fp32 sum.
+#include "common.h"
+
+struct ConvArgs {
+    const float* src;
+    const float* wt;
+    float* dst;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    const float* resid;
+    float* stats;
+    unsigned long long tap_dhdw;  // 4 bits per tap: (dh+1) | (dw+1) << 2
+    unsigned long long tap_wsel;  // 4 bits per tap: weight slice
+    int H, W, C, logC, cmask, src_ld;
+    int OH, OW, sh, sw;
+    int DH, DW, dsh, dsw, doh, dow, dst_ld, dense_dst;
+    int resid_ld;
+    int Nout, K, M;
+    unsigned flags;
+    float alpha;
+    int nbn;
+};
+
+template <int BM, int BN, int WM, int WN, int BK>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs p) {
+    constexpr int THREADS = 64 * WM * WN;
+    constexpr int LDA = BK + 4;
+    constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
+    constexpr int KV = BK / 4;
+    constexpr int A_TOTAL = BM * KV, A_LOADS = (A_TOTAL + THREADS - 1) / THREADS;
+    constexpr int BN4 = BN / 4;
+    constexpr int B_TOTAL = BK * BN4, B_LOADS = (B_TOTAL + THREADS - 1) / THREADS;
+    static_assert(THREADS % KV == 0 && TM % 32 == 0 && TN % 32 == 0, "tile shape");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+    __shared__ float red[2][WM][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int bid = y3_xcd_remap(blockIdx.x, gridDim.x);
+    const int bm = bid / p.nbn, bn = bid % p.nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    // ---- per-thread A rows (pixel decomposition is K-invariant)
+    int a_pix[A_LOADS], a_ih0[A_LOADS], a_iw0[A_LOADS];
+    bool a_ok[A_LOADS];
+    const int a_kv = tid % KV;
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int idx = tid + i * THREADS;
+        const int row = idx / KV;
+        const int m = m0 + row;
+        const bool ok = (idx < A_TOTAL) && (m < p.M);
+        const int mm = ok ? m : 0;
+        const int n = mm / ohw;
+        const int r = mm - n * ohw;
+        const int oh = r / p.OW;
+        const int ow = r - oh * p.OW;
+        a_ih0[i] = oh * p.sh;
+        a_iw0[i] = ow * p.sw;
+        a_pix[i] = (n * p.H + a_ih0[i]) * p.W + a_iw0[i];
+        a_ok[i] = ok;
+    }
+    const bool n_aligned = (p.Nout & 3) == 0;
+
+    float4 ra[A_LOADS], rb[B_LOADS];
+    auto gload = [&](int k0) {
+        {
+            const int k = k0 + a_kv * 4;
+            const int tap = k >> p.logC;
+            const int c = k & p.cmask;
+            const int code = (int)((p.tap_dhdw >> (4 * tap)) & 15ull);
+            const int dh = (code & 3) - 1, dw = (code >> 2) - 1;
+            const int doff = dh * p.W + dw;
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) {
+                const int ih = a_ih0[i] + dh, iw = a_iw0[i] + dw;
+                const bool ok = a_ok[i] && (k < p.K) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) {
+                    v = *reinterpret_cast<const float4*>(p.src + ((long long)(a_pix[i] + doff) * p.src_ld + c));
+                    if (k + 4 > p.K) {  // K tail (K % 4 != 0): zero the lanes past K
+                        if (k + 1 >= p.K) v.y = 0.f;
+                        if (k + 2 >= p.K) v.z = 0.f;
+                        if (k + 3 >= p.K) v.w = 0.f;
+                    }
+                }
+                ra[i] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int idx = tid + i * THREADS;
+            const int kr = idx / BN4, n4 = idx % BN4;
+            const int k = k0 + kr;
+            const int n = n0 + n4 * 4;
+            const int tap = k >> p.logC;
+            const int c = k & p.cmask;
+            const int ws = (int)((p.tap_wsel >> (4 * tap)) & 15ull);
+            const float* g = p.wt + ((long long)(ws * p.C + c) * p.Nout + n);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < B_TOTAL && k < p.K) {
+                if (n_aligned) {
+                    if (n < p.Nout) v = *reinterpret_cast<const float4*>(g);
+                } else {
+                    if (n < p.Nout) v.x = g[0];
+                    if (n + 1 < p.Nout) v.y = g[1];
+                    if (n + 2 < p.Nout) v.z = g[2];
+                    if (n + 3 < p.Nout) v.w = g[3];
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int idx = tid + i * THREADS;
+            if (idx < A_TOTAL) *reinterpret_cast<float4*>(&As[buf][(idx / KV) * LDA + a_kv * 4]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int idx = tid + i * THREADS;
+            if (idx < B_TOTAL) *reinterpret_cast<float4*>(&Bs[buf][(idx / BN4) * BN + (idx % BN4) * 4]) = rb[i];
+        }
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        const bool more = ks + 1 < nk;
+        if (more) gload((ks + 1) * BK);
+        const float* as = &As[cur][(wm * TM + l31) * LDA + lh * 4];
+        const float* bs = &Bs[cur][(lh * 4) * BN + wn * TN + l31];
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float4 av[MB];
+            float bv[NB][4];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) av[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDA + kk * 8);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[j][q] = bs[(kk * 8 + q) * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j][3], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool do_lrelu = p.flags & Y3_EPI_LRELU;
+    const bool do_accum = p.flags & Y3_EPI_ACCUM;
+    float ssum[NB], ssq[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) ssum[j] = ssq[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * TN + j * 32 + l31;
+        const bool nok = n < p.Nout;
+        const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+        const float sc = (p.scale && nok) ? p.scale[n] : 1.f;
+        const float sf = (p.scale && nok) ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < p.M && nok) {
+                    float v = acc[i][j][r] + bias;
+                    if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
+                    ssum[j] += v;
+                    ssq[j] += v * v;
+                    long long pix;
+                    if (p.dense_dst) {
+                        pix = m;
+                    } else {
+                        const int nimg = m / ohw;
+                        const int rr = m - nimg * ohw;
+                        const int oh = rr / p.OW;
+                        const int ow = rr - oh * p.OW;
+                        pix = ((long long)nimg * p.DH + oh * p.dsh + p.doh) * p.DW + ow * p.dsw + p.dow;
+                    }
+                    if (p.scale) v = v * sc + sf;
+                    if (p.resid) v += p.resid[pix * p.resid_ld + n];
+                    float* d = p.dst + pix * p.dst_ld + n;
+                    if (do_accum) v += *d;
+                    *d = v;
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        // per-(row tile, channel) partial sums for training-mode BatchNorm: combine the two
+        // half-waves, then the WM waves stacked along M, in a fixed order (deterministic)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float s = ssum[j] + __shfl_xor(ssum[j], 32);
+            const float q = ssq[j] + __shfl_xor(ssq[j], 32);
+            if (lh == 0) {
+                red[0][wm][wn * TN + j * 32 + l31] = s;
+                red[1][wm][wn * TN + j * 32 + l31] = q;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < 2 * BN; c += THREADS) {
+            const int which = c / BN, col = c % BN;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) s += red[which][w][col];
+            const int n = n0 + col;
+            if (n < p.Nout) p.stats[((long long)bm * 2 + which) * p.Nout + n] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// kernel gradient: out[z][k][n] = sum_{m in chunk z} A[m][k] * ddst[m][n]
+// ---------------------------------------------------------------------------
+struct WgradArgs {
+    const float* src;
+    const float* ddst;
+    float* out;
+    unsigned long long tap_dhdw;
+    int H, W, C, logC, cmask, src_ld;
+    int OH, OW, sh, sw;
+    int dd_ld, Nout, K, M;
+    int chunk;  // pixels per split (multiple of BP)
+    int nbn;
+};
+
+template <int BKR, int BN, int WM, int WN, int BP>
+__global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(const WgradArgs p) {
+    constexpr int THREADS = 64 * WM * WN;
+    constexpr int TM = BKR / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
+    constexpr int KR4 = BKR / 4, BN4 = BN / 4;
+    constexpr int A_TOTAL = BP * KR4, A_LOADS = (A_TOTAL + THREADS - 1) / THREADS;
+    constexpr int B_TOTAL = BP * BN4, B_LOADS = (B_TOTAL + THREADS - 1) / THREADS;
+    static_assert(THREADS % KR4 == 0 && THREADS % BN4 == 0, "loader shape");
+    constexpr int A_PSTEP = THREADS / KR4;  // pixel distance between a thread's consecutive A loads
+    constexpr int B_PSTEP = THREADS / BN4;
+
+    __shared__ __attribute__((aligned(16))) float At[2][BP * BKR];
+    __shared__ __attribute__((aligned(16))) float Bt[2][BP * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int bid = y3_xcd_remap(blockIdx.x, gridDim.x);
+    const int bk = bid / p.nbn, bn = bid % p.nbn;
+    const int k0 = bk * BKR, n0 = bn * BN;
+    const int mbeg = blockIdx.y * p.chunk;
+    const int mend = min(p.M, mbeg + p.chunk);
+
+    // A: this thread always loads the same 4 k's (tap, c..c+3); only the pixel advances
+    const int a_kv = tid % KR4;
+    const int ak = k0 + a_kv * 4;
+    const bool ak_ok = ak < p.K;
+    const int atap = ak_ok ? (ak >> p.logC) : 0;
+    const int ac = ak & p.cmask;
+    const int acode = (int)((p.tap_dhdw >> (4 * atap)) & 15ull);
+    const int adh = (acode & 3) - 1, adw = (acode >> 2) - 1;
+    int a_n[A_LOADS], a_oh[A_LOADS], a_ow[A_LOADS], a_m[A_LOADS];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int pp = tid / KR4 + i * A_PSTEP;
+        const int m = mbeg + pp;
+        a_m[i] = m;
+        const int n = m / ohw;
+        const int r = m - n * ohw;
+        a_n[i] = n;
+        a_oh[i] = r / p.OW;
+        a_ow[i] = r - a_oh[i] * p.OW;
+    }
+    const int b_n4 = tid % BN4;
+    const int bnn = n0 + b_n4 * 4;
+    const bool bn_ok = bnn < p.Nout;
+
+    float4 ra[A_LOADS], rb[B_LOADS];
+    auto gload = [&](int step) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int pp = tid / KR4 + i * A_PSTEP;
+            const int ih = a_oh[i] * p.sh + adh, iw = a_ow[i] * p.sw + adw;
+            const bool ok = ak_ok && pp < BP && a_m[i] < mend && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                v = *reinterpret_cast<const float4*>(p.src + (((long long)a_n[i] * p.H + ih) * p.W + iw) * p.src_ld + ac);
+                if (ak + 4 > p.K) {
+                    if (ak + 1 >= p.K) v.y = 0.f;
+                    if (ak + 2 >= p.K) v.z = 0.f;
+                    if (ak + 3 >= p.K) v.w = 0.f;
+                }
+            }
+            ra[i] = v;
+            // advance this slot's pixel by BP for the next step
+            a_m[i] += BP;
+            a_ow[i] += BP;
+            while (a_ow[i] >= p.OW) {
+                a_ow[i] -= p.OW;
+                if (++a_oh[i] == p.OH) {
+                    a_oh[i] = 0;
+                    ++a_n[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int pp = tid / BN4 + i * B_PSTEP;
+            const int m = mbeg + step * BP + pp;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pp < BP && m < mend && bn_ok) v = *reinterpret_cast<const float4*>(p.ddst + (long long)m * p.dd_ld + bnn);
+            rb[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int pp = tid / KR4 + i * A_PSTEP;
+            if (pp < BP) *reinterpret_cast<float4*>(&At[buf][pp * BKR + a_kv * 4]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int pp = tid / BN4 + i * B_PSTEP;
+            if (pp < BP) *reinterpret_cast<float4*>(&Bt[buf][pp * BN + b_n4 * 4]) = rb[i];
+        }
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nsteps = (mend > mbeg) ? (mend - mbeg + BP - 1) / BP : 0;
+    if (nsteps > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int st = 0; st < nsteps; ++st) {
+        const bool more = st + 1 < nsteps;
+        if (more) gload(st + 1);
+        const float* as = &At[cur][lh * BKR + wm * TM + l31];
+        const float* bs = &Bt[cur][lh * BN + wn * TN + l31];
+#pragma unroll
+        for (int pp = 0; pp < BP / 2; ++pp) {
+            float av[MB], bv[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) av[i] = as[pp * 2 * BKR + i * 32];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bv[j] = bs[pp * 2 * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float* out = p.out + (long long)blockIdx.y * p.K * p.Nout;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * TN + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (k < p.K && n < p.Nout) out[(long long)k * p.Nout + n] = acc[i][j][r];
+            }
+    }
+}
+
+// dst[i] = sum_z slabs[z][i]   (float4; count multiple of 4 guaranteed by caller padding or tail loop)
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dst, long long count, int nslabs) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        float s = 0.f;
+        for (int z = 0; z < nslabs; ++z) s += slabs[(long long)z * count + i];
+        dst[i] = s;
+    }
+}
+
+__global__ void transpose_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int cin, int cout) {
+    // one 32x32 tile per block, blockIdx.z = tap;  wt[t][co][ci] = w[t][ci][co]
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+    const float* src = w + (long long)t * cin * cout;
+    float* dst = wt + (long long)t * cin * cout;
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        tile[r][tx] = (ci < cin && co < cout) ? src[(long long)ci * cout + co] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        if (ci < cin && co < cout) dst[(long long)co * cin + ci] = tile[tx][r];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static int check_tensor(const y3_tensor* t, const char* name) {
+    Y3_CHECK_ARG(t && t->ptr, "%s: null tensor", name);
+    Y3_CHECK_ARG(t->n > 0 && t->h > 0 && t->w > 0 && t->c > 0 && t->ld >= t->c, "%s: bad dims n=%d h=%d w=%d c=%d ld=%d", name,
+                 t->n, t->h, t->w, t->c, t->ld);
+    Y3_CHECK_ARG((t->ld & 3) == 0, "%s: ld=%d must be a multiple of 4", name, t->ld);
+    Y3_CHECK_ARG(((uintptr_t)t->ptr & 15) == 0, "%s: pointer must be 16-byte aligned", name);
+    return 0;
+}
+
+struct TileCfg {
+    int bm, bn;
+};
+
+// pick the tile that keeps the most SIMDs busy for this (M, Nout)
+static TileCfg pick_tile(int M, int Nout) {
+    if (Nout <= 32) return {128, 32};
+    if (Nout <= 64) return {128, 64};
+    const long long big = (long long)y3_cdiv(M, 128) * y3_cdiv(Nout, 128);
+    if (big >= 256) return {128, 128};
+    return {64, 64};
+}
+
+int y3_conv2d_stats_tiles(int m, int cout) {
+    TileCfg t = pick_tile(m, cout);
+    return y3_cdiv(m, t.bm);
+}
+
+static int launch_igemm(const ConvArgs& a, hipStream_t st) {
+    ConvArgs p = a;
+    const TileCfg t = pick_tile(p.M, p.Nout);
+    p.nbn = y3_cdiv(p.Nout, t.bn);
+    const int grid = y3_cdiv(p.M, t.bm) * p.nbn;
+    if (t.bm == 128 && t.bn == 128)
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, 16>), dim3(grid), dim3(256), 0, st, p);
+    else if (t.bm == 128 && t.bn == 64)
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 4, 1, 16>), dim3(grid), dim3(256), 0, st, p);
+    else if (t.bm == 128 && t.bn == 32)
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, 16>), dim3(grid), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, 16>), dim3(grid), dim3(256), 0, st, p);
+    Y3_CHECK_LAUNCH("conv_igemm");
+    return Y3_OK;
+}
+
+static int set_channels(int C, int taps, int* logC, int* cmask) {
+    if (taps == 1) {
+        *logC = 31;
+        *cmask = 0x7fffffff;
+        return 0;
+    }
+    Y3_CHECK_ARG(y3_is_pow2(C) && C >= 4, "3x3 conv needs power-of-two channels >= 4 (got %d)", C);
+    *logC = y3_ilog2(C);
+    *cmask = C - 1;
+    return 0;
+}
+
+extern "C" int y3_conv2d_fwd(const y3_tensor* src, const float* wt, const float* bias, int ksize, int stride, const y3_tensor* dst,
+                             unsigned flags, float alpha, const float* scale, const float* shift, const y3_tensor* resid, float* stats,
+                             y3_stream_t stream) {
+    if (int e = check_tensor(src, "conv2d_fwd src")) return e;
+    if (int e = check_tensor(dst, "conv2d_fwd dst")) return e;
+    Y3_CHECK_ARG(wt, "conv2d_fwd: null weights");
+    Y3_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_fwd: ksize %d unsupported", ksize);
+    Y3_CHECK_ARG(stride == 1 || stride == 2, "conv2d_fwd: stride %d unsupported", stride);
+    Y3_CHECK_ARG((src->c & 3) == 0, "conv2d_fwd: Cin=%d must be a multiple of 4", src->c);
+    const int OH = (src->h + stride - 1) / stride, OW = (src->w + stride - 1) / stride;
+    Y3_CHECK_ARG(dst->n == src->n && dst->h == OH && dst->w == OW, "conv2d_fwd: dst geometry %dx%dx%d != expected %dx%dx%d", dst->n,
+                 dst->h, dst->w, src->n, OH, OW);
+    Y3_CHECK_ARG((scale == nullptr) == (shift == nullptr), "conv2d_fwd: scale/shift must both be given");
+    ConvArgs p = {};
+    p.src = src->ptr;
+    p.wt = wt;
+    p.dst = dst->ptr;
+    p.bias = bias;
+    p.scale = scale;
+    p.shift = shift;
+    p.stats = stats;
+    if (resid) {
+        if (int e = check_tensor(resid, "conv2d_fwd resid")) return e;
+        Y3_CHECK_ARG(resid->n == dst->n && resid->h == dst->h && resid->w == dst->w && resid->c == dst->c, "conv2d_fwd: resid geometry");
+        p.resid = resid->ptr;
+        p.resid_ld = resid->ld;
+    }
+    const int taps = ksize * ksize;
+    if (int e = set_channels(src->c, taps, &p.logC, &p.cmask)) return e;
+    const int pbh = y3_same_pad_before(src->h, ksize, stride), pbw = y3_same_pad_before(src->w, ksize, stride);
+    for (int kh = 0; kh < ksize; ++kh)
+        for (int kw = 0; kw < ksize; ++kw) {
+            const int t = kh * ksize + kw;
+            const int dh = kh - pbh, dw = kw - pbw;
+            Y3_CHECK_ARG(dh >= -1 && dh <= 2 && dw >= -1 && dw <= 2, "conv2d_fwd: tap offset out of range");
+            p.tap_dhdw |= (unsigned long long)((dh + 1) | ((dw + 1) << 2)) << (4 * t);
+            p.tap_wsel |= (unsigned long long)t << (4 * t);
+        }
+    p.H = src->h;
+    p.W = src->w;
+    p.C = src->c;
+    p.src_ld = src->ld;
+    p.OH = OH;
+    p.OW = OW;
+    p.sh = p.sw = stride;
+    p.DH = OH;
+    p.DW = OW;
+    p.dsh = p.dsw = 1;
+    p.dst_ld = dst->ld;
+    p.dense_dst = 1;
+    p.Nout = dst->c;
+    p.K = taps * src->c;
+    p.M = src->n * OH * OW;
+    p.flags = flags;
+    p.alpha = alpha;
+    return launch_igemm(p, (hipStream_t)stream);
+}
+
+extern "C" int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc, unsigned flags,
+                               y3_stream_t stream) {
+    if (int e = check_tensor(ddst, "conv2d_dgrad ddst")) return e;
+    if (int e = check_tensor(dsrc, "conv2d_dgrad dsrc")) return e;
+    Y3_CHECK_ARG(wt_t, "conv2d_dgrad: null weights");
+    Y3_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_dgrad: ksize %d unsupported", ksize);
+    Y3_CHECK_ARG(stride == 1 || stride == 2, "conv2d_dgrad: stride %d unsupported", stride);
+    const int OH = (dsrc->h + stride - 1) / stride, OW = (dsrc->w + stride - 1) / stride;
+    Y3_CHECK_ARG(ddst->n == dsrc->n && ddst->h == OH && ddst->w == OW, "conv2d_dgrad: geometry mismatch");
+    Y3_CHECK_ARG((flags & ~Y3_EPI_ACCUM) == 0, "conv2d_dgrad: only Y3_EPI_ACCUM allowed");
+    const int pbh = y3_same_pad_before(dsrc->h, ksize, stride), pbw = y3_same_pad_before(dsrc->w, ksize, stride);
+    // the contraction runs over (tap, cout): channels of ddst
+    ConvArgs base = {};
+    base.src = ddst->ptr;
+    base.wt = wt_t;
+    base.dst = dsrc->ptr;
+    base.H = ddst->h;
+    base.W = ddst->w;
+    base.C = ddst->c;
+    base.src_ld = ddst->ld;
+    base.dst_ld = dsrc->ld;
+    base.Nout = dsrc->c;
+    base.flags = flags;
+    base.DH = dsrc->h;
+    base.DW = dsrc->w;
+    base.sh = base.sw = 1;
+    if (stride == 1) {
+        ConvArgs p = base;
+        const int taps = ksize * ksize;
+        if (int e = set_channels(ddst->c, taps, &p.logC, &p.cmask)) return e;
+        for (int kh = 0; kh < ksize; ++kh)
+            for (int kw = 0; kw < ksize; ++kw) {
+                const int t = kh * ksize + kw;
+                const int dh = pbh - kh, dw = pbw - kw;  // dsrc[i] += ddst[i + pad - k] * w[k]
+                p.tap_dhdw |= (unsigned long long)((dh + 1) | ((dw + 1) << 2)) << (4 * t);
+                p.tap_wsel |= (unsigned long long)t << (4 * t);
+            }
+        p.OH = dsrc->h;
+        p.OW = dsrc->w;
+        p.dsh = p.dsw = 1;
+        p.dense_dst = 1;
+        p.K = taps * ddst->c;
+        p.M = dsrc->n * p.OH * p.OW;
+        return launch_igemm(p, (hipStream_t)stream);
+    }
+    // stride 2: forward out o reads in[2o + k - pad]; input pixel i = 2q + par receives from the taps with
+    // (par + pad - k) even, at o = q + (par + pad - k)/2.  One launch per (row parity, col parity).
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            ConvArgs p = base;
+            int nt = 0;
+            for (int kh = 0; kh < ksize; ++kh) {
+                if ((ph + pbh - kh) & 1) continue;
+                for (int kw = 0; kw < ksize; ++kw) {
+                    if ((pw + pbw - kw) & 1) continue;
+                    const int dh = (ph + pbh - kh) / 2, dw = (pw + pbw - kw) / 2;  // exact: numerator even (may be negative)
+                    Y3_CHECK_ARG(dh >= -1 && dh <= 2 && dw >= -1 && dw <= 2, "conv2d_dgrad: tap offset out of range");
+                    p.tap_dhdw |= (unsigned long long)((dh + 1) | ((dw + 1) << 2)) << (4 * nt);
+                    p.tap_wsel |= (unsigned long long)(kh * ksize + kw) << (4 * nt);
+                    ++nt;
+                }
+            }
+            p.OH = (dsrc->h - ph + 1) / 2;
+            p.OW = (dsrc->w - pw + 1) / 2;
+            if (p.OH <= 0 || p.OW <= 0) continue;
+            p.dsh = p.dsw = 2;
+            p.doh = ph;
+            p.dow = pw;
+            p.dense_dst = 0;
+            p.M = dsrc->n * p.OH * p.OW;
+            if (nt == 0) {
+                // no tap reaches this parity class (1x1 stride 2): gradient is zero there
+                Y3_CHECK_ARG(false, "conv2d_dgrad: 1x1 stride-2 not supported");
+            }
+            if (int e = set_channels(ddst->c, nt == 1 ? 1 : 9, &p.logC, &p.cmask)) return e;
+            if (nt == 1) {  // single tap: plain k = c (no power-of-two requirement)
+                p.logC = 31;
+                p.cmask = 0x7fffffff;
+            }
+            p.K = nt * ddst->c;
+            if (int e = launch_igemm(p, (hipStream_t)stream)) return e;
+        }
+    return Y3_OK;
+}
+
+// ---- wgrad ---------------------------------------------------------------
+struct WgradPlan {
+    int bkr, bn, splits, chunk, tiles;
+};
+static WgradPlan plan_wgrad(int K, int Nout, int M) {
+    WgradPlan w;
+    w.bkr = (K <= 64) ? 64 : 128;
+    w.bn = (Nout <= 32) ? 32 : (Nout <= 64 ? 64 : 128);
+    w.tiles = y3_cdiv(K, w.bkr) * y3_cdiv(Nout, w.bn);
+    // aim at ~4 workgroups per CU overall, at least 256 pixels per split
+    int splits = y3_cdiv(1024, w.tiles);
+    const int maxs = y3_cdiv(M, 256);
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+    int chunk = y3_cdiv(M, splits);
+    chunk = y3_cdiv(chunk, 16) * 16;
+    w.splits = y3_cdiv(M, chunk);
+    w.chunk = chunk;
+    return w;
+}
+
+extern "C" size_t y3_conv2d_wgrad_workspace(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride) {
+    (void)stride;
+    const int K = ksize * ksize * src->c;
+    const int M = ddst->n * ddst->h * ddst->w;
+    const WgradPlan w = plan_wgrad(K, ddst->c, M);
+    return w.splits > 1 ? (size_t)w.splits * K * ddst->c * sizeof(float) : 0;
+}
+
+extern "C" int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride, float* dw, void* workspace,
+                               size_t workspace_bytes, y3_stream_t stream) {
+    if (int e = check_tensor(src, "conv2d_wgrad src")) return e;
+    if (int e = check_tensor(ddst, "conv2d_wgrad ddst")) return e;
+    Y3_CHECK_ARG(dw, "conv2d_wgrad: null dw");
+    Y3_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_wgrad: ksize %d unsupported", ksize);
+    Y3_CHECK_ARG(stride == 1 || stride == 2, "conv2d_wgrad: stride %d unsupported", stride);
+    Y3_CHECK_ARG((src->c & 3) == 0, "conv2d_wgrad: Cin=%d must be a multiple of 4", src->c);
+    const int OH = (src->h + stride - 1) / stride, OW = (src->w + stride - 1) / stride;
+    Y3_CHECK_ARG(ddst->n == src->n && ddst->h == OH && ddst->w == OW, "conv2d_wgrad: geometry mismatch");
+    WgradArgs p = {};
+    const int taps = ksize * ksize;
+    if (int e = set_channels(src->c, taps, &p.logC, &p.cmask)) return e;
+    const int pbh = y3_same_pad_before(src->h, ksize, stride), pbw = y3_same_pad_before(src->w, ksize, stride);
+    for (int kh = 0; kh < ksize; ++kh)
+        for (int kw = 0; kw < ksize; ++kw) {
+            const int t = kh * ksize + kw;
+            p.tap_dhdw |= (unsigned long long)((kh - pbh + 1) | ((kw - pbw + 1) << 2)) << (4 * t);
+        }
+    p.src = src->ptr;
+    p.ddst = ddst->ptr;
+    p.H = src->h;
+    p.W = src->w;
+    p.C = src->c;
+    p.src_ld = src->ld;
+    p.OH = OH;
+    p.OW = OW;
+    p.sh = p.sw = stride;
+    p.dd_ld = ddst->ld;
+    p.Nout = ddst->c;
+    p.K = taps * src->c;
+    p.M = src->n * OH * OW;
+    const WgradPlan w = plan_wgrad(p.K, p.Nout, p.M);
+    p.chunk = w.chunk;
+    p.nbn = y3_cdiv(p.Nout, w.bn);
+    const size_t need = w.splits > 1 ? (size_t)w.splits * p.K * p.Nout * sizeof(float) : 0;
+    Y3_CHECK_ARG(workspace_bytes >= need && (need == 0 || workspace), "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
+    p.out = w.splits > 1 ? (float*)workspace : dw;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(w.tiles, w.splits);
+    if (w.bkr == 128 && w.bn == 128)
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 16>), grid, dim3(256), 0, st, p);
+    else if (w.bkr == 128 && w.bn == 64)
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 4, 1, 16>), grid, dim3(256), 0, st, p);
+    else if (w.bkr == 128 && w.bn == 32)
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 4, 1, 16>), grid, dim3(256), 0, st, p);
+    else if (w.bkr == 64 && w.bn == 128)
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2, 16>), grid, dim3(256), 0, st, p);
+    else if (w.bkr == 64 && w.bn == 64)
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, 16>), grid, dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 32, 2, 1, 16>), grid, dim3(128), 0, st, p);
+    Y3_CHECK_LAUNCH("conv_wgrad");
+    if (w.splits > 1) {
+        const long long count = (long long)p.K * p.Nout;
+        const int blocks = (int)((count + 255) / 256 > 2048 ? 2048 : (count + 255) / 256);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, count, w.splits);
+        Y3_CHECK_LAUNCH("slab_reduce");
+    }
+    return Y3_OK;
+}
+
+extern "C" int y3_transpose_weights(const float* wt, float* wt_t, int taps, int cin, int cout, y3_stream_t stream) {
+    Y3_CHECK_ARG(wt && wt_t && taps > 0 && cin > 0 && cout > 0, "transpose_weights: bad args");
+    dim3 grid(y3_cdiv(cout, 32), y3_cdiv(cin, 32), taps);
+    hipLaunchKernelGGL(transpose_weights_kernel, grid, dim3(256), 0, (hipStream_t)stream, wt, wt_t, cin, cout);
+    Y3_CHECK_LAUNCH("transpose_weights");
+    return Y3_OK;
+}

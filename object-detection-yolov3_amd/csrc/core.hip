@@ -1,0 +1,14 @@
+// Error channel and version of libyolo3hip.so.
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void y3_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* y3_last_error(void) { return g_err; }
+extern "C" int y3_version(void) { return 1; }

@@ -1,0 +1,592 @@
+// HBM-bound kernels around the convolutions: BatchNorm (training statistics,
+// apply, backward), the all-ones upsample, concat copies, gradient fan-in,
+// layout changes, Adam, z-score.  All are streaming kernels: 16-byte accesses
+// along the contiguous channel axis, grid-stride loops capped at ~8 blocks/CU.
+#include "common.h"
+
+static inline int stream_blocks(long long items, int threads) {
+    long long b = (items + threads - 1) / threads;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+static int check_view(const y3_tensor* t, const char* name) {
+    Y3_CHECK_ARG(t && t->ptr, "%s: null tensor", name);
+    Y3_CHECK_ARG(t->n > 0 && t->h > 0 && t->w > 0 && t->c > 0 && t->ld >= t->c, "%s: bad dims", name);
+    return 0;
+}
+static int check_view4(const y3_tensor* t, const char* name) {
+    if (int e = check_view(t, name)) return e;
+    Y3_CHECK_ARG((t->c & 3) == 0 && (t->ld & 3) == 0 && ((uintptr_t)t->ptr & 15) == 0, "%s: needs c, ld multiples of 4 and 16-byte alignment", name);
+    return 0;
+}
+static inline long long pixels(const y3_tensor* t) { return (long long)t->n * t->h * t->w; }
+static inline bool same_geom(const y3_tensor* a, const y3_tensor* b) { return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c; }
+
+// ---------------------------------------------------------------------------
+// BatchNorm training statistics
+// ---------------------------------------------------------------------------
+// block = 32 partial-lanes x 32 channels; fp64 accumulation of the fp32 partials
+__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const float* __restrict__ stats, int tiles, int C, double inv_count,
+                                                                 double bessel, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps, float momentum,
+                                                                 float* moving_mean, float* moving_var, float* save_mean,
+                                                                 float* save_rstd, float* scale, float* shift) {
+    __shared__ double sm[2][32][33];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int t = g; t < tiles; t += 32) {
+            s += (double)stats[((long long)t * 2 + 0) * C + c];
+            q += (double)stats[((long long)t * 2 + 1) * C + c];
+        }
+    sm[0][g][cl] = s;
+    sm[1][g][cl] = q;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        s = 0.0;
+        q = 0.0;
+        for (int i = 0; i < 32; ++i) {
+            s += sm[0][i][cl];
+            q += sm[1][i][cl];
+        }
+        const double mean = s * inv_count;
+        double var = q * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float fmean = (float)mean;
+        const float sc = gamma[c] * rstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - fmean * sc;
+        save_mean[c] = fmean;
+        save_rstd[c] = rstd;
+        if (moving_mean) {
+            moving_mean[c] = moving_mean[c] * momentum + fmean * (1.f - momentum);
+            moving_var[c] = moving_var[c] * momentum + (float)(var * bessel) * (1.f - momentum);
+        }
+    }
+}
+
+extern "C" int y3_bn_stats_finalize(const float* stats, int tiles, int c, int count, const float* gamma, const float* beta, float eps,
+                                    float momentum, float* moving_mean, float* moving_var, float* save_mean, float* save_rstd,
+                                    float* scale, float* shift, y3_stream_t stream) {
+    Y3_CHECK_ARG(stats && gamma && beta && save_mean && save_rstd && scale && shift, "bn_stats_finalize: null pointer");
+    Y3_CHECK_ARG(tiles > 0 && c > 0 && count > 0, "bn_stats_finalize: bad sizes");
+    Y3_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "bn_stats_finalize: moving stats must both be given");
+    const double bessel = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(y3_cdiv(c, 32)), dim3(1024), 0, (hipStream_t)stream, stats, tiles, c, 1.0 / (double)count,
+                       bessel, gamma, beta, eps, momentum, moving_mean, moving_var, save_mean, save_rstd, scale, shift);
+    Y3_CHECK_LAUNCH("bn_stats_finalize");
+    return Y3_OK;
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int C, float* scale,
+                               float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float sc = gamma[c] * (1.f / sqrtf(var[c] + eps));
+        scale[c] = sc;
+        shift[c] = beta[c] - mean[c] * sc;
+    }
+}
+extern "C" int y3_bn_fold_inference(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var, float eps,
+                                    int c, float* scale, float* shift, y3_stream_t stream) {
+    Y3_CHECK_ARG(gamma && beta && moving_mean && moving_var && scale && shift && c > 0, "bn_fold_inference: bad args");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(y3_cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, moving_mean, moving_var, eps, c,
+                       scale, shift);
+    Y3_CHECK_LAUNCH("bn_fold_inference");
+    return Y3_OK;
+}
+
+// y = a*scale + shift (+ resid)
+__global__ void bn_apply_kernel(const float* __restrict__ a, int a_ld, const float* __restrict__ scale, const float* __restrict__ shift,
+                                const float* __restrict__ resid, int r_ld, float* __restrict__ y, int y_ld, long long npix, int c4) {
+    const long long total = npix * c4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long long pix = i / c4;
+        const int c = (int)(i - pix * c4) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(a + pix * a_ld + c);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+        const float4 sf = *reinterpret_cast<const float4*>(shift + c);
+        float4 o = make_float4(v.x * sc.x + sf.x, v.y * sc.y + sf.y, v.z * sc.z + sf.z, v.w * sc.w + sf.w);
+        if (resid) {
+            const float4 r = *reinterpret_cast<const float4*>(resid + pix * r_ld + c);
+            o.x += r.x;
+            o.y += r.y;
+            o.z += r.z;
+            o.w += r.w;
+        }
+        *reinterpret_cast<float4*>(y + pix * y_ld + c) = o;
+    }
+}
+extern "C" int y3_bn_apply(const y3_tensor* a, const float* scale, const float* shift, const y3_tensor* resid, const y3_tensor* y,
+                           y3_stream_t stream) {
+    if (int e = check_view4(a, "bn_apply a")) return e;
+    if (int e = check_view4(y, "bn_apply y")) return e;
+    Y3_CHECK_ARG(same_geom(a, y) && scale && shift, "bn_apply: geometry/pointers");
+    if (resid) {
+        if (int e = check_view4(resid, "bn_apply resid")) return e;
+        Y3_CHECK_ARG(same_geom(a, resid), "bn_apply: resid geometry");
+    }
+    const long long total = pixels(a) * (a->c / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, a->ptr, a->ld, scale, shift,
+                       resid ? resid->ptr : nullptr, resid ? resid->ld : 0, y->ptr, y->ld, pixels(a), a->c / 4);
+    Y3_CHECK_LAUNCH("bn_apply");
+    return Y3_OK;
+}
+
+// ---------------------------------------------------------------------------
+// BatchNorm + leaky-relu backward
+// ---------------------------------------------------------------------------
+#define Y3_BNB_MAXPARTS 512
+extern "C" int y3_bn_bwd_partials(int m, int c) {
+    if (c < 4 || c > 1024) return 1;
+    const int rows_per_pass = 256 / (c / 4);
+    int parts = y3_cdiv(m, (long long)rows_per_pass * 4);
+    if (parts > Y3_BNB_MAXPARTS) parts = Y3_BNB_MAXPARTS;
+    if (parts < 1) parts = 1;
+    return parts;
+}
+
+// partials[part][5][C]: sum dy, sum dy*xhat, sum dy*s, sum s, sum xhat*s   (s = lrelu slope at a)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int dy_ld, const float* __restrict__ a, int a_ld,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd, float alpha,
+                                                            float* __restrict__ partials, long long npix, int C) {
+    __shared__ float sm[256 * 20];
+    const int c4n = C >> 2;
+    const int rpp = 256 / c4n;
+    const int cq = threadIdx.x % c4n, rg = threadIdx.x / c4n;
+    const int c = cq * 4;
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+    const float4 rs = *reinterpret_cast<const float4*>(rstd + c);
+    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+    float acc[5][4];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] = 0.f;
+    const long long rows_per_block = (npix + gridDim.x - 1) / gridDim.x;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > npix) r1 = npix;
+    for (long long r = r0 + rg; r < r1; r += rpp) {
+        const float4 d4 = *reinterpret_cast<const float4*>(dy + r * dy_ld + c);
+        const float4 a4 = *reinterpret_cast<const float4*>(a + r * a_ld + c);
+        const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (av[e] - muv[e]) * rsv[e];
+            const float s = av[e] > 0.f ? 1.f : alpha;
+            acc[0][e] += dv[e];
+            acc[1][e] += dv[e] * xh;
+            acc[2][e] += dv[e] * s;
+            acc[3][e] += s;
+            acc[4][e] += xh * s;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sm[threadIdx.x * 20 + j * 4 + e] = acc[j][e];
+    __syncthreads();
+    if (rg == 0) {
+        for (int g = 1; g < rpp; ++g)
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][e] += sm[(g * c4n + cq) * 20 + j * 4 + e];
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            *reinterpret_cast<float4*>(partials + ((long long)blockIdx.x * 5 + j) * C + c) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+    }
+}
+
+extern "C" int y3_bn_bwd_reduce(const y3_tensor* dy, const y3_tensor* a, const float* save_mean, const float* save_rstd, float alpha,
+                                float* partials, int* nparts, y3_stream_t stream) {
+    if (int e = check_view4(dy, "bn_bwd_reduce dy")) return e;
+    if (int e = check_view4(a, "bn_bwd_reduce a")) return e;
+    Y3_CHECK_ARG(same_geom(dy, a) && save_mean && save_rstd && partials, "bn_bwd_reduce: geometry/pointers");
+    Y3_CHECK_ARG(a->c <= 1024 && 256 % (a->c / 4) == 0, "bn_bwd_reduce: channels %d unsupported", a->c);
+    const int parts = y3_bn_bwd_partials((int)pixels(a), a->c);
+    if (nparts) *nparts = parts;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, dy->ptr, dy->ld, a->ptr, a->ld, save_mean,
+                       save_rstd, alpha, partials, pixels(a), a->c);
+    Y3_CHECK_LAUNCH("bn_bwd_reduce");
+    return Y3_OK;
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, double inv_count,
+                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, float* dgamma, float* dbeta,
+                                                               float* dbias, float* coef) {
+    __shared__ double sm[5][32][33];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s[5] = {0, 0, 0, 0, 0};
+    if (c < C)
+        for (int t = g; t < nparts; t += 32)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) s[j] += (double)partials[((long long)t * 5 + j) * C + c];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) sm[j][g][cl] = s[j];
+    __syncthreads();
+    if (g == 0 && c < C) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            double t = 0.0;
+            for (int i = 0; i < 32; ++i) t += sm[j][i][cl];
+            s[j] = t;
+        }
+        const double db = s[0], dg = s[1], sdys = s[2], ss = s[3], sxs = s[4];
+        const double ga = gamma[c], r = rstd[c], mu = mean[c];
+        // da = ga*r*(dy - db/M - xhat*dg/M);  dz = da*slope;  dbias = sum dz
+        dgamma[c] = (float)dg;
+        dbeta[c] = (float)db;
+        dbias[c] = (float)(ga * r * (sdys - db * inv_count * ss - dg * inv_count * sxs));
+        const double k1 = ga * r;
+        const double k2 = -ga * r * r * dg * inv_count;
+        const double k3 = -ga * r * db * inv_count - k2 * mu;
+        coef[c] = (float)k1;
+        coef[C + c] = (float)k2;
+        coef[2 * C + c] = (float)k3;
+    }
+}
+extern "C" int y3_bn_bwd_finalize(const float* partials, int nparts, int c, int count, const float* gamma, const float* save_mean,
+                                  const float* save_rstd, float alpha, float* dgamma, float* dbeta, float* dbias, float* coef,
+                                  y3_stream_t stream) {
+    (void)alpha;
+    Y3_CHECK_ARG(partials && gamma && save_mean && save_rstd && dgamma && dbeta && dbias && coef, "bn_bwd_finalize: null pointer");
+    Y3_CHECK_ARG(nparts > 0 && c > 0 && count > 0, "bn_bwd_finalize: bad sizes");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(y3_cdiv(c, 32)), dim3(1024), 0, (hipStream_t)stream, partials, nparts, c,
+                       1.0 / (double)count, gamma, save_mean, save_rstd, dgamma, dbeta, dbias, coef);
+    Y3_CHECK_LAUNCH("bn_bwd_finalize");
+    return Y3_OK;
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_ld, const float* __restrict__ a, int a_ld,
+                                    const float* __restrict__ coef, float alpha, float* __restrict__ dz, int dz_ld, long long npix, int C) {
+    const int c4n = C >> 2;
+    const long long total = npix * c4n;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long long pix = i / c4n;
+        const int c = (int)(i - pix * c4n) * 4;
+        const float4 d4 = *reinterpret_cast<const float4*>(dy + pix * dy_ld + c);
+        const float4 a4 = *reinterpret_cast<const float4*>(a + pix * a_ld + c);
+        const float4 k1 = *reinterpret_cast<const float4*>(coef + c);
+        const float4 k2 = *reinterpret_cast<const float4*>(coef + C + c);
+        const float4 k3 = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+        float4 o;
+        o.x = (k1.x * d4.x + k2.x * a4.x + k3.x) * (a4.x > 0.f ? 1.f : alpha);
+        o.y = (k1.y * d4.y + k2.y * a4.y + k3.y) * (a4.y > 0.f ? 1.f : alpha);
+        o.z = (k1.z * d4.z + k2.z * a4.z + k3.z) * (a4.z > 0.f ? 1.f : alpha);
+        o.w = (k1.w * d4.w + k2.w * a4.w + k3.w) * (a4.w > 0.f ? 1.f : alpha);
+        *reinterpret_cast<float4*>(dz + pix * dz_ld + c) = o;
+    }
+}
+extern "C" int y3_bn_bwd_apply(const y3_tensor* dy, const y3_tensor* a, const float* coef, float alpha, const y3_tensor* dz,
+                               y3_stream_t stream) {
+    if (int e = check_view4(dy, "bn_bwd_apply dy")) return e;
+    if (int e = check_view4(a, "bn_bwd_apply a")) return e;
+    if (int e = check_view4(dz, "bn_bwd_apply dz")) return e;
+    Y3_CHECK_ARG(same_geom(dy, a) && same_geom(dy, dz) && coef, "bn_bwd_apply: geometry/pointers");
+    const long long total = pixels(a) * (a->c / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, dy->ptr, dy->ld, a->ptr,
+                       a->ld, coef, alpha, dz->ptr, dz->ld, pixels(a), a->c);
+    Y3_CHECK_LAUNCH("bn_bwd_apply");
+    return Y3_OK;
+}
+
+// ---------------------------------------------------------------------------
+// upsample_2x = frozen all-ones Conv2DTranspose(k2,s2): a channel sum, broadcast
+// ---------------------------------------------------------------------------
+// one wave per input pixel
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ in, int in_ld, int C, float* __restrict__ out, int out_ld,
+                                                           int outC, int N, int H, int W) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long npix = (long long)N * H * W;
+    if (wave >= npix) return;
+    const float* src = in + wave * in_ld;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(src + c);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    s = y3_wave_sum(s);
+    const int n = (int)(wave / ((long long)H * W));
+    const int r = (int)(wave - (long long)n * H * W);
+    const int i = r / W, j = r - i * W;
+    const float4 o = make_float4(s, s, s, s);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float* dst = out + (((long long)n * 2 * H + 2 * i + a) * 2 * W + 2 * j + b) * out_ld;
+            for (int c = lane * 4; c < outC; c += 256) *reinterpret_cast<float4*>(dst + c) = o;
+        }
+}
+extern "C" int y3_upsample_sum2x_fwd(const y3_tensor* in, const y3_tensor* out, y3_stream_t stream) {
+    if (int e = check_view4(in, "upsample_fwd in")) return e;
+    if (int e = check_view4(out, "upsample_fwd out")) return e;
+    Y3_CHECK_ARG(out->n == in->n && out->h == 2 * in->h && out->w == 2 * in->w, "upsample_fwd: geometry");
+    const long long npix = pixels(in);
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(y3_cdiv(npix, 4)), dim3(256), 0, (hipStream_t)stream, in->ptr, in->ld, in->c, out->ptr,
+                       out->ld, out->c, in->n, in->h, in->w);
+    Y3_CHECK_LAUNCH("upsample_fwd");
+    return Y3_OK;
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dout, int do_ld, int outC, float* __restrict__ din,
+                                                           int di_ld, int C, int N, int H, int W) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long npix = (long long)N * H * W;
+    if (wave >= npix) return;
+    const int n = (int)(wave / ((long long)H * W));
+    const int r = (int)(wave - (long long)n * H * W);
+    const int i = r / W, j = r - i * W;
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float* src = dout + (((long long)n * 2 * H + 2 * i + a) * 2 * W + 2 * j + b) * do_ld;
+            for (int c = lane * 4; c < outC; c += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(src + c);
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+        }
+    s = y3_wave_sum(s);
+    const float4 o = make_float4(s, s, s, s);
+    float* dst = din + wave * di_ld;
+    for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(dst + c) = o;
+}
+extern "C" int y3_upsample_sum2x_bwd(const y3_tensor* dout, const y3_tensor* din, y3_stream_t stream) {
+    if (int e = check_view4(dout, "upsample_bwd dout")) return e;
+    if (int e = check_view4(din, "upsample_bwd din")) return e;
+    Y3_CHECK_ARG(dout->n == din->n && dout->h == 2 * din->h && dout->w == 2 * din->w, "upsample_bwd: geometry");
+    const long long npix = pixels(din);
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(y3_cdiv(npix, 4)), dim3(256), 0, (hipStream_t)stream, dout->ptr, dout->ld, dout->c, din->ptr,
+                       din->ld, din->c, din->n, din->h, din->w);
+    Y3_CHECK_LAUNCH("upsample_bwd");
+    return Y3_OK;
+}
+
+// ---------------------------------------------------------------------------
+// data movement
+// ---------------------------------------------------------------------------
+template <bool ADD>
+__global__ void copy_add_kernel(const float* __restrict__ src, int s_ld, float* __restrict__ dst, int d_ld, long long npix, int c4n) {
+    const long long total = npix * c4n;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long long pix = i / c4n;
+        const int c = (int)(i - pix * c4n) * 4;
+        float4 v = *reinterpret_cast<const float4*>(src + pix * s_ld + c);
+        if (ADD) {
+            const float4 d = *reinterpret_cast<const float4*>(dst + pix * d_ld + c);
+            v.x += d.x;
+            v.y += d.y;
+            v.z += d.z;
+            v.w += d.w;
+        }
+        *reinterpret_cast<float4*>(dst + pix * d_ld + c) = v;
+    }
+}
+template <bool ADD>
+static int copy_add(const y3_tensor* src, const y3_tensor* dst, y3_stream_t stream, const char* what) {
+    if (int e = check_view4(src, what)) return e;
+    if (int e = check_view4(dst, what)) return e;
+    Y3_CHECK_ARG(same_geom(src, dst), "%s: geometry", what);
+    const long long total = pixels(src) * (src->c / 4);
+    hipLaunchKernelGGL((copy_add_kernel<ADD>), dim3(stream_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, src->ptr, src->ld, dst->ptr,
+                       dst->ld, pixels(src), src->c / 4);
+    Y3_CHECK_LAUNCH(what);
+    return Y3_OK;
+}
+extern "C" int y3_copy(const y3_tensor* src, const y3_tensor* dst, y3_stream_t stream) { return copy_add<false>(src, dst, stream, "copy"); }
+extern "C" int y3_add_inplace(const y3_tensor* src, const y3_tensor* dst, y3_stream_t stream) {
+    return copy_add<true>(src, dst, stream, "add_inplace");
+}
+
+__global__ void fill_kernel(float* p, size_t count, float v) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) p[i] = v;
+}
+extern "C" int y3_fill(float* ptr, size_t count, float value, y3_stream_t stream) {
+    Y3_CHECK_ARG(ptr || count == 0, "fill: null pointer");
+    if (count == 0) return Y3_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(stream_blocks((long long)count, 256)), dim3(256), 0, (hipStream_t)stream, ptr, count, value);
+    Y3_CHECK_LAUNCH("fill");
+    return Y3_OK;
+}
+
+// [N,C,H,W] -> NHWC with channel padding: one thread per (pixel), reads C planes (coalesced along W)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, int C, long long hw, float* __restrict__ dst, int d_ld, int dC, long long npix) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+        const long long n = i / hw, r = i - n * hw;
+        for (int c = 0; c < dC; ++c) dst[i * d_ld + c] = c < C ? src[(n * C + c) * hw + r] : 0.f;
+    }
+}
+extern "C" int y3_nchw_to_nhwc(const float* src, int n, int c, int h, int w, const y3_tensor* dst, y3_stream_t stream) {
+    if (int e = check_view(dst, "nchw_to_nhwc dst")) return e;
+    Y3_CHECK_ARG(src && dst->n == n && dst->h == h && dst->w == w && dst->c >= c, "nchw_to_nhwc: geometry");
+    const long long npix = (long long)n * h * w;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(stream_blocks(npix, 256)), dim3(256), 0, (hipStream_t)stream, src, c, (long long)h * w, dst->ptr,
+                       dst->ld, dst->c, npix);
+    Y3_CHECK_LAUNCH("nchw_to_nhwc");
+    return Y3_OK;
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int s_ld, int C, long long hw, float* __restrict__ dst, long long total) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long long r = i % hw;
+        const long long nc = i / hw;
+        const long long n = nc / C;
+        const int c = (int)(nc - n * C);
+        dst[i] = src[(n * hw + r) * s_ld + c];
+    }
+}
+extern "C" int y3_nhwc_to_nchw(const y3_tensor* src, float* dst, y3_stream_t stream) {
+    if (int e = check_view(src, "nhwc_to_nchw src")) return e;
+    Y3_CHECK_ARG(dst, "nhwc_to_nchw: null dst");
+    const long long total = pixels(src) * src->c;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(stream_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, src->ptr, src->ld, src->c,
+                       (long long)src->h * src->w, dst, total);
+    Y3_CHECK_LAUNCH("nhwc_to_nchw");
+    return Y3_OK;
+}
+
+// out[c] = sum over pixels; single block, fp64 accumulation, fixed order (deterministic)
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ src, int ld, int C, long long npix, float* __restrict__ out) {
+    __shared__ double sm[1024];
+    for (int c = 0; c < C; ++c) {
+        double s = 0.0;
+        for (long long r = threadIdx.x; r < npix; r += 1024) s += (double)src[r * ld + c];
+        sm[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[c] = (float)sm[0];
+        __syncthreads();
+    }
+}
+extern "C" int y3_colsum(const y3_tensor* src, float* out, y3_stream_t stream) {
+    if (int e = check_view(src, "colsum src")) return e;
+    Y3_CHECK_ARG(out && src->c <= 1024, "colsum: meant for the detection heads (c <= 1024)");
+    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, src->ptr, src->ld, src->c, pixels(src), out);
+    Y3_CHECK_LAUNCH("colsum");
+    return Y3_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Keras Adam (App. C5), fused over the whole parameter arena
+// ---------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t count4,
+                            size_t count, const float* __restrict__ lr_t_dev, float b1, float b2, float eps) {
+    const float lr_t = *lr_t_dev;
+    const float o1 = 1.f - b1, o2 = 1.f - b2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+#define Y3_ADAM1(f)                              \
+    mm.f += (gg.f - mm.f) * o1;                  \
+    vv.f += (gg.f * gg.f - vv.f) * o2;           \
+    pp.f -= (mm.f * lr_t) / (sqrtf(vv.f) + eps);
+        Y3_ADAM1(x) Y3_ADAM1(y) Y3_ADAM1(z) Y3_ADAM1(w)
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    // tail
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
+        const size_t i = (count4 << 2) + threadIdx.x;
+        float mm = m[i], vv = v[i];
+        mm += (g[i] - mm) * o1;
+        vv += (g[i] * g[i] - vv) * o2;
+        p[i] -= (mm * lr_t) / (sqrtf(vv) + eps);
+        m[i] = mm;
+        v[i] = vv;
+    }
+}
+extern "C" int y3_adam_step(float* param, const float* grad, float* m, float* v, size_t count, const float* lr_t_dev, float beta1, float beta2,
+                            float eps, y3_stream_t stream) {
+    Y3_CHECK_ARG(param && grad && m && v && lr_t_dev, "adam_step: null pointer");
+    Y3_CHECK_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: arenas must be 16-byte aligned");
+    if (count == 0) return Y3_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks((long long)(count / 4 + 1), 256)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
+                       count / 4, count, lr_t_dev, beta1, beta2, eps);
+    Y3_CHECK_LAUNCH("adam_step");
+    return Y3_OK;
+}
+
+// ---------------------------------------------------------------------------
+// z-score (imagereader.py:34-46): per image mean / population std, fp64 partials
+// ---------------------------------------------------------------------------
+#define Y3_ZS_BLOCKS 128
+__global__ __launch_bounds__(256) void zscore_partial_kernel(const float* __restrict__ in, size_t count, double* __restrict__ ws) {
+    __shared__ double sm[2][256];
+    const int img = blockIdx.y;
+    const float* src = in + (size_t)img * count;
+    double s = 0.0, q = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)Y3_ZS_BLOCKS * 256) {
+        const double v = (double)src[i];
+        s += v;
+        q += v * v;
+    }
+    sm[0][threadIdx.x] = s;
+    sm[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            sm[0][threadIdx.x] += sm[0][threadIdx.x + o];
+            sm[1][threadIdx.x] += sm[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        ws[((size_t)img * Y3_ZS_BLOCKS + blockIdx.x) * 2 + 0] = sm[0][0];
+        ws[((size_t)img * Y3_ZS_BLOCKS + blockIdx.x) * 2 + 1] = sm[1][0];
+    }
+}
+__global__ void zscore_apply_kernel(const float* __restrict__ in, float* __restrict__ out, size_t count, const double* __restrict__ ws) {
+    const int img = blockIdx.y;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < Y3_ZS_BLOCKS; ++b) {  // every thread re-reduces the 128 partials (L2-resident, fixed order)
+        s += ws[((size_t)img * Y3_ZS_BLOCKS + b) * 2 + 0];
+        q += ws[((size_t)img * Y3_ZS_BLOCKS + b) * 2 + 1];
+    }
+    const double mean = s / (double)count;
+    double var = q / (double)count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mv = (float)mean, sd = (float)sqrt(var);
+    const float* src = in + (size_t)img * count;
+    float* dst = out + (size_t)img * count;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    if (sd <= 1.0f) {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[i] = src[i] - mv;
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[i] = (src[i] - mv) / sd;
+    }
+}
+extern "C" size_t y3_zscore_workspace_bytes(int n) { return (size_t)n * Y3_ZS_BLOCKS * 2 * sizeof(double); }
+extern "C" int y3_zscore(const float* in, float* out, int n, size_t count, void* workspace, y3_stream_t stream) {
+    Y3_CHECK_ARG(in && out && workspace && n > 0 && count > 0, "zscore: bad args");
+    hipLaunchKernelGGL(zscore_partial_kernel, dim3(Y3_ZS_BLOCKS, n), dim3(256), 0, (hipStream_t)stream, in, count, (double*)workspace);
+    Y3_CHECK_LAUNCH("zscore_partial");
+    int blocks = stream_blocks((long long)count, 256);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(zscore_apply_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, in, out, count, (const double*)workspace);
+    Y3_CHECK_LAUNCH("zscore_apply");
+    return Y3_OK;
+}

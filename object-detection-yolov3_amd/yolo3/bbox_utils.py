@@ -1,0 +1,127 @@
+"""Host mirror of the reference's bbox_utils.py (NMS part on the GPU).
+
+per_class_nms / filter_small_boxes keep the reference signatures
+(bbox_utils.py:240-281) but run the class-wise NMS kernel (csrc/detect.hip);
+``detect`` is the fused entry the CLIs use: clip -> small-box filter ->
+class-wise NMS on device-resident ``[N, Nb, 5+K]`` rows, no host round trip
+of the candidates.  CSV writers follow bbox_utils.py:47-62 and 284-300.
+"""
+import numpy as np
+import torch
+
+from ._hip import lib, check
+
+
+class _NmsBuffers:
+    def __init__(self, n, nb, k, device):
+        self.key = (n, nb, k, str(device))
+        self.keep_idx = torch.empty(n, k, nb, dtype=torch.int32, device=device)
+        self.keep_cnt = torch.zeros(n, k, dtype=torch.int32, device=device)
+        self.keep_score = torch.empty(n, k, nb, dtype=torch.float32, device=device)
+        self.ws_bytes = int(lib.y3_nms_workspace_bytes(n, nb, k))
+        self.ws = torch.empty(self.ws_bytes // 4 + 4, dtype=torch.float32, device=device)
+
+
+_cache = {}
+
+
+def nms_device(rows, min_box_size=0.0, iou_threshold=0.3, score_threshold=0.1, clip_wh=None):
+    """rows: CUDA float32 [N, Nb, 5+K].  Returns (keep_idx[N,K,Nb] int32,
+    keep_cnt[N,K] int32, keep_score[N,K,Nb]) device tensors; entries beyond
+    keep_cnt are undefined."""
+    assert rows.is_cuda and rows.dtype == torch.float32 and rows.dim() == 3
+    rows = rows.contiguous()
+    n, nb, d = rows.shape
+    k = d - 5
+    key = (n, nb, k, str(rows.device))
+    buf = _cache.get(key)
+    if buf is None:
+        buf = _cache[key] = _NmsBuffers(n, nb, k, rows.device)
+    cw, chh = (float(clip_wh[0]), float(clip_wh[1])) if clip_wh is not None else (-1.0, -1.0)
+    st = torch.cuda.current_stream(rows.device).cuda_stream
+    check(lib.y3_nms_per_class(rows.data_ptr(), n, nb, k, float(min_box_size), float(score_threshold), float(iou_threshold), cw, chh,
+                               buf.keep_idx.data_ptr(), buf.keep_cnt.data_ptr(), buf.keep_score.data_ptr(), nb, buf.ws.data_ptr(),
+                               buf.ws_bytes, st), 'y3_nms_per_class')
+    return buf.keep_idx, buf.keep_cnt, buf.keep_score
+
+
+def detect(rows, min_box_size, iou_threshold=0.3, score_threshold=0.1, clip_wh=None):
+    """inference.py:62-79 for a batch: returns, per image, (boxes[M,4], score[M],
+    label[M] int32, keep[M] row indices) as NumPy arrays, or (None,)*4."""
+    keep_idx, keep_cnt, keep_score = nms_device(rows, min_box_size, iou_threshold, score_threshold, clip_wh)
+    cnt = keep_cnt.cpu().numpy()
+    n, nb, d = rows.shape
+    k = d - 5
+    out = []
+    for i in range(n):
+        if cnt[i].sum() == 0:
+            out.append((None, None, None, None))
+            continue
+        idx = torch.cat([keep_idx[i, c, :cnt[i, c]] for c in range(k)]).long()
+        sc = torch.cat([keep_score[i, c, :cnt[i, c]] for c in range(k)])
+        lab = np.concatenate([np.ones(cnt[i, c], dtype='int32') * c for c in range(k)])
+        boxes = rows[i, idx, 0:4]
+        if clip_wh is not None:
+            boxes = boxes.clone()
+            boxes[:, 0::2] = boxes[:, 0::2].clamp(0, float(clip_wh[0]))
+            boxes[:, 1::2] = boxes[:, 1::2].clamp(0, float(clip_wh[1]))
+        out.append((boxes.cpu().numpy(), sc.cpu().numpy(), lab, idx.cpu().numpy().astype(np.int32)))
+    return out
+
+
+def per_class_nms(boxes, objectness, class_probs, iou_threshold=0.3, score_threshold=0.1):
+    """bbox_utils.py:240-271 (same signature and (None, None, None) convention)."""
+    boxes = np.asarray(boxes, np.float32)
+    rows = np.concatenate([boxes, np.asarray(objectness, np.float32).reshape(-1, 1), np.asarray(class_probs, np.float32)], axis=1)
+    if rows.shape[0] == 0:
+        return None, None, None
+    r = torch.from_numpy(rows).cuda()[None]
+    b, s, l, _ = detect(r, -np.inf, iou_threshold, score_threshold)[0]
+    return b, s, l
+
+
+def single_class_nms(boxes, scores, iou_threshold):
+    """bbox_utils.py:217-237: keep indices (selection order) into ``boxes``."""
+    boxes = np.asarray(boxes, np.float32)
+    scores = np.asarray(scores, np.float32).reshape(-1, 1)
+    m = boxes.shape[0]
+    if m == 0:
+        return []
+    rows = torch.from_numpy(np.ascontiguousarray(np.concatenate([boxes, scores], axis=1))).cuda()
+    keep_idx = torch.empty(m, dtype=torch.int32, device=rows.device)
+    keep_cnt = torch.zeros(1, dtype=torch.int32, device=rows.device)
+    keep_score = torch.empty(m, dtype=torch.float32, device=rows.device)
+    ws_bytes = int(lib.y3_nms_workspace_bytes(1, m, 1))
+    ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=rows.device)
+    st = torch.cuda.current_stream(rows.device).cuda_stream
+    check(lib.y3_nms_single_class(rows.data_ptr(), m, float(iou_threshold), keep_idx.data_ptr(), keep_cnt.data_ptr(), keep_score.data_ptr(),
+                                  ws.data_ptr(), ws_bytes, st), 'y3_nms_single_class')
+    return [int(v) for v in keep_idx[:int(keep_cnt.item())].cpu().numpy()]
+
+
+def filter_small_boxes(boxes, min_size):
+    """bbox_utils.py:274-281 (strict '>'); host NumPy like the reference -- the
+    CLIs use the fused device path in ``detect`` instead."""
+    w = boxes[:, 2] - boxes[:, 0]
+    h = boxes[:, 3] - boxes[:, 1]
+    return boxes[np.logical_and(w > min_size, h > min_size), :]
+
+
+def write_boxes_from_xywhc(boxes, csv_filename):
+    """bbox_utils.py:47-62."""
+    with open(csv_filename, 'w') as fh:
+        fh.write('X,Y,W,H,C\n')
+        for k in range(boxes.shape[0]):
+            fh.write('{:d},{:d},{:d},{:d},{:d}\n'.format(int(boxes[k, 0]), int(boxes[k, 1]), int(boxes[k, 2]), int(boxes[k, 3]), int(boxes[k, 4])))
+
+
+def write_boxes_from_ltrbpc(boxes, csv_filename):
+    """bbox_utils.py:284-300: W = x2 - x + 1."""
+    with open(csv_filename, 'w') as fh:
+        fh.write('X,Y,W,H,P,C\n')
+        for k in range(boxes.shape[0]):
+            x = int(boxes[k, 0])
+            y = int(boxes[k, 1])
+            w = int(boxes[k, 2] - x + 1)
+            h = int(boxes[k, 3] - y + 1)
+            fh.write('{:d},{:d},{:d},{:d},{:f},{:d}\n'.format(x, y, w, h, boxes[k, 4], int(boxes[k, 5])))

@@ -1,0 +1,770 @@
+"""YoloV3 on MI355X: host-side mirror of the reference's ``model.YoloV3``
+(/root/reference/model.py:19-540) driving hand-written HIP kernels through the
+C ABI in include/yolo3hip.h.
+
+Same constructor, methods and tensor contracts as the reference class
+(model.py:423-540): NCHW z-scored images in, ``[N, Nb, 5+K]`` detections out,
+three ``[N, G, G, A, 5+K]`` label tensors for the loss.  Internally everything
+is NHWC fp32 in HBM (channel-contiguous = GEMM-K-contiguous), parameters /
+gradients / Adam moments live in flat arenas in Keras ``trainable_weights``
+order, and each step is a static list of kernel launches (replayable as one
+HIP graph).  torch is used for device memory, streams and the RCCL all-reduce
+only; there is no torch.nn / autograd / CPU fallback on this path.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _hip
+from ._hip import lib, check, view, EPI_LRELU, EPI_ACCUM
+
+BN_EPS = 1e-3          # Keras BatchNormalization defaults
+BN_MOMENTUM = 0.99
+LRELU_ALPHA = 0.2      # tf.nn.leaky_relu default (App. C3)
+ALIGN = 64             # arena alignment in floats (256 B)
+
+
+def _round_up(v, a):
+    return (v + a - 1) // a * a
+
+
+class LayerSpec:
+    __slots__ = ('cin', 'cin_pad', 'cout', 'k', 's', 'bn', 'w_off', 'b_off', 'g_off', 'be_off', 'end_off', 'bn_idx', 'ch_off', 'mv_off')
+
+
+def build_layer_specs(in_channels, num_anchors, num_classes):
+    """Conv layers in Keras creation order (model.py:356-421); see the walk in
+    ``_Plan._build`` which consumes them in the same order."""
+    L = []
+
+    def conv(cin, cout, k, s=1, bn=True):
+        sp = LayerSpec()
+        sp.cin, sp.cout, sp.k, sp.s, sp.bn = cin, cout, k, s, bn
+        sp.cin_pad = _round_up(cin, 4)
+        L.append(sp)
+        return cout
+
+    def feature_block(c, reps):
+        for _ in range(reps):
+            conv(c, c // 2, 1)
+            conv(c // 2, c, 3)
+        return c
+
+    FC = YoloV3.FILTER_COUNT
+    c = conv(in_channels, FC // 32, 3)
+    c = conv(c, FC // 16, 3, 2)
+    c = feature_block(c, 1)
+    c = conv(c, FC // 8, 3, 2)
+    c = feature_block(c, 2)
+    c = conv(c, FC // 4, 3, 2)
+    c = feature_block(c, YoloV3.BLOCK_COUNT)
+    c = conv(c, FC // 2, 3, 2)
+    c = feature_block(c, YoloV3.BLOCK_COUNT)
+    c = conv(c, FC, 3, 2)
+    c = feature_block(c, YoloV3.BLOCK_COUNT // 2)
+    D = num_anchors * (5 + num_classes)
+
+    def yolo_block(cin, fc):
+        for i in range(3):
+            conv(cin if i == 0 else fc, fc // 2, 1)
+            conv(fc // 2, fc, 3)
+
+    yolo_block(FC, FC)
+    conv(FC, D, 1, 1, bn=False)
+    conv(FC // 2, FC // 2, 1)
+    yolo_block(FC, FC // 2)
+    conv(FC // 2, D, 1, 1, bn=False)
+    conv(FC // 4, FC // 4, 1)
+    yolo_block(FC // 2, FC // 4)
+    conv(FC // 4, D, 1, 1, bn=False)
+    # arena offsets (floats)
+    off = 0
+    bn_idx = 0
+    ch = 0
+    mv = 0
+    for sp in L:
+        sp.w_off = off
+        off = _round_up(off + sp.k * sp.k * sp.cin_pad * sp.cout, ALIGN)
+        sp.b_off = off
+        off = _round_up(off + sp.cout, ALIGN)
+        if sp.bn:
+            sp.g_off = off
+            off = _round_up(off + sp.cout, ALIGN)
+            sp.be_off = off
+            off = _round_up(off + sp.cout, ALIGN)
+            sp.bn_idx = bn_idx
+            bn_idx += 1
+            sp.ch_off = ch                  # per-layer block [scale|shift|save_mean|save_rstd|k1|k2|k3], each cout floats
+            ch = _round_up(ch + 7 * sp.cout, ALIGN)
+            sp.mv_off = mv                  # offset into the moving mean / variance arrays
+            mv = _round_up(mv + sp.cout, ALIGN)
+        else:
+            sp.g_off = sp.be_off = -1
+            sp.bn_idx = -1
+            sp.ch_off = sp.mv_off = -1
+        sp.end_off = off
+    return L, off, ch, mv
+
+
+class _T:
+    """An NHWC activation (or a channel slice of one) plus its gradient twin."""
+
+    def __init__(self, buf, n, h, w, c, ld=None, off=0):
+        self.buf, self.n, self.h, self.w, self.c = buf, n, h, w, c
+        self.ld = c if ld is None else ld
+        self.off = off
+        self.v = view(buf, n, h, w, c, self.ld, off)
+        self.grad = None
+        self.gw = False           # gradient already holds a contribution (next writer accumulates)
+        self.children = []
+        self.parent = None
+
+    @property
+    def m(self):
+        return self.n * self.h * self.w
+
+    def slice(self, c0, c):
+        t = _T(self.buf, self.n, self.h, self.w, c, self.ld, self.off + c0)
+        t.parent = self
+        self.children.append(t)
+        return t
+
+    def mark_written(self):
+        self.gw = True
+        for ch in self.children:
+            ch.gw = True
+
+    def torch_view(self):
+        """[N,H,W,C] strided torch view (debug / export)."""
+        flat = self.buf.view(-1)
+        return torch.as_strided(flat, (self.n, self.h, self.w, self.c), (self.h * self.w * self.ld, self.w * self.ld, self.ld, 1), self.off)
+
+
+class Mean:
+    """Minimal stand-in for tf.keras.metrics.Mean (train.py:80-90)."""
+
+    def __init__(self, name='mean', dtype=None):
+        self.name = name
+        self.reset_states()
+
+    def update_state(self, value):
+        self.total = self.total + (value.detach() if torch.is_tensor(value) else float(value))
+        self.count += 1
+
+    def result(self):
+        if self.count == 0:
+            return 0.0
+        t = self.total / self.count
+        return float(t.item()) if torch.is_tensor(t) else float(t)
+
+    def reset_states(self):
+        self.total = 0.0
+        self.count = 0
+
+
+class _Plan:
+    """Static launch list for one (batch size, mode)."""
+
+    def __init__(self, model, n, training):
+        self.model = model
+        self.n = n
+        self.training = training
+        self.fwd = []      # [(cfunc, args)]   stream appended at run time
+        self.bwd = []
+        self.keep = []     # ctypes objects / tensors that must outlive the lists
+        self.graph = None
+        self._build()
+
+    # -- allocation helpers -------------------------------------------------
+    def _new(self, n, h, w, c, ld=None, zero=False):
+        ld = c if ld is None else ld
+        numel = n * h * w * ld
+        buf = (torch.zeros if zero else torch.empty)(numel, dtype=torch.float32, device=self.model.device)
+        return _T(buf, n, h, w, c, ld)
+
+    def _emit(self, lst, fn, *args):
+        self.keep.append(args)
+        lst.append((fn, args))
+
+    # -- network walk (model.py:356-421) ---------------------------------------
+    def _build(self):
+        mdl = self.model
+        dev = mdl.device
+        N = self.n
+        H, W, C = mdl.img_size
+        A, K = mdl.number_anchors, mdl.number_classes
+        D = A * (5 + K)
+        Dld = _round_up(D, 4)
+        specs = mdl.specs
+        P = mdl.params
+        tr = self.training
+        self.in_nchw = torch.zeros(N, C, H, W, dtype=torch.float32, device=dev)
+        self.ops = []      # high-level records for the backward emission
+        li = [0]
+
+        x0 = self._new(N, H, W, specs[0].cin_pad, zero=True)
+        self._emit(self.fwd, lib.y3_nchw_to_nhwc, self.in_nchw.data_ptr(), N, C, H, W, x0.v)
+
+        # shared workspaces.  The largest M*Cout of the net is conv1's (full resolution, FILTER_COUNT/32
+        # channels); BN partial statistics need <= 2*Cout floats per row tile of >= 64 rows.
+        max_mc = N * H * W * max(YoloV3.FILTER_COUNT // 32, Dld)
+        self.stats_ws = torch.empty(max_mc // 32 + 4096, dtype=torch.float32, device=dev)
+        if tr:
+            self.dz = torch.empty(max_mc, dtype=torch.float32, device=dev)
+            self.bnb_ws = torch.empty(512 * 5 * 1024, dtype=torch.float32, device=dev)
+            self.wg_ws_bytes = 0
+
+        def ptr(off):
+            return P.data_ptr() + 4 * off
+
+        def conv_layer(src, out=None, resid=None):
+            """model.py:29-39 (+ the tf.add of model.py:47 when resid is given)."""
+            i = li[0]
+            li[0] += 1
+            sp = specs[i]
+            oh, ow = -(-src.h // sp.s), -(-src.w // sp.s)
+            y = out if out is not None else self._new(N, oh, ow, sp.cout)
+            ch = mdl.chan.data_ptr() + 4 * sp.ch_off       # per-layer [scale|shift|mean|rstd|coef(3)] block
+            cs = sp.cout * 4
+            scale, shift, smean, srstd, coef = ch, ch + cs, ch + 2 * cs, ch + 3 * cs, ch + 4 * cs
+            mmean = mdl.moving.data_ptr() + 4 * sp.mv_off
+            mvar = mdl.moving.data_ptr() + 4 * (mdl.moving_stride + sp.mv_off)
+            if tr:
+                a = self._new(N, oh, ow, sp.cout)
+                tiles = lib.y3_conv2d_stats_tiles(a.m, sp.cout)
+                self._emit(self.fwd, lib.y3_conv2d_fwd, src.v, ptr(sp.w_off), ptr(sp.b_off), sp.k, sp.s, a.v, EPI_LRELU, LRELU_ALPHA,
+                           None, None, None, self.stats_ws.data_ptr())
+                self._emit(self.fwd, lib.y3_bn_stats_finalize, self.stats_ws.data_ptr(), tiles, sp.cout, a.m, ptr(sp.g_off), ptr(sp.be_off),
+                           BN_EPS, BN_MOMENTUM, mmean, mvar, smean, srstd, scale, shift)
+                self._emit(self.fwd, lib.y3_bn_apply, a.v, scale, shift, resid.v if resid is not None else None, y.v)
+                self.ops.append(('conv_layer', i, src, a, y, resid, (smean, srstd, coef)))
+            else:
+                self._emit(self.fwd, lib.y3_bn_fold_inference, ptr(sp.g_off), ptr(sp.be_off), mmean, mvar, BN_EPS, sp.cout, scale, shift)
+                self._emit(self.fwd, lib.y3_conv2d_fwd, src.v, ptr(sp.w_off), ptr(sp.b_off), sp.k, sp.s, y.v, EPI_LRELU, LRELU_ALPHA,
+                           scale, shift, resid.v if resid is not None else None, None)
+            return y
+
+        def feature_block(inp, reps, out_last=None):
+            """model.py:42-48: every repetition adds the BLOCK input (Q2)."""
+            layer = inp
+            for r in range(reps):
+                layer = conv_layer(layer)
+                layer = conv_layer(layer, out=out_last if r == reps - 1 else None, resid=inp)
+            return layer
+
+        def yolo_block(inp):
+            for _ in range(5):
+                inp = conv_layer(inp)
+            return inp, conv_layer(inp)
+
+        def head(src, g):
+            """detection_layer (model.py:108-120): linear 1x1 conv, bias."""
+            i = li[0]
+            li[0] += 1
+            sp = specs[i]
+            fm = self._new(N, src.h, src.w, D, Dld, zero=True)
+            self._emit(self.fwd, lib.y3_conv2d_fwd, src.v, ptr(sp.w_off), ptr(sp.b_off), 1, 1, fm.v, 0, 0.0, None, None, None, None)
+            self.ops.append(('head', i, src, fm))
+            return fm
+
+        def upsample_into(src, dst):
+            self._emit(self.fwd, lib.y3_upsample_sum2x_fwd, src.v, dst.v)
+            self.ops.append(('upsample', src, dst))
+
+        FC = YoloV3.FILTER_COUNT
+        g1h, g1w = H // 32, W // 32
+        cat2 = self._new(N, g1h * 2, g1w * 2, FC)              # tf.concat([up(512), route2(512)])  model.py:368
+        cat3 = self._new(N, g1h * 4, g1w * 4, FC // 2)         # tf.concat([up(256), route1(256)])  model.py:375
+        cat2_up, cat2_rt = cat2.slice(0, FC // 2), cat2.slice(FC // 2, FC // 2)
+        cat3_up, cat3_rt = cat3.slice(0, FC // 4), cat3.slice(FC // 4, FC // 4)
+
+        x = conv_layer(x0)
+        x = conv_layer(x)
+        x = feature_block(x, 1)
+        x = conv_layer(x)
+        x = feature_block(x, 2)
+        x = conv_layer(x)
+        route1 = x = feature_block(x, YoloV3.BLOCK_COUNT, out_last=cat3_rt)
+        x = conv_layer(x)
+        route2 = x = feature_block(x, YoloV3.BLOCK_COUNT, out_last=cat2_rt)
+        x = conv_layer(x)
+        route3 = feature_block(x, YoloV3.BLOCK_COUNT // 2)
+
+        route, x = yolo_block(route3)
+        fm1 = head(x, 0)
+        x = conv_layer(route)
+        upsample_into(x, cat2_up)
+        route, x = yolo_block(cat2)
+        fm2 = head(x, 1)
+        x = conv_layer(route)
+        upsample_into(x, cat3_up)
+        route, x = yolo_block(cat3)
+        fm3 = head(x, 2)
+        assert li[0] == len(specs)
+        self.fms = [fm1, fm2, fm3]
+        self.x0 = x0
+
+        # decode (model.py:169-212)
+        self.nb = sum(f.h * f.w * A for f in self.fms)
+        self.boxes = torch.empty(N, self.nb, 5 + K, dtype=torch.float32, device=dev)
+        self.fm_arr = (_hip.Tensor * 3)(*[f.v for f in self.fms])
+        self.decode_call = (lib.y3_decode_fwd, (self.fm_arr, 3, mdl.anchors_c, A, K, H, W, self.boxes.data_ptr()))
+
+        # loss (model.py:214-354): always available (test_step needs it in inference mode too)
+        self.gt = [torch.zeros(N, f.h, f.w, A, 5 + K, dtype=torch.float32, device=dev) for f in self.fms]
+        self.loss4 = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.loss_ws = torch.zeros(int(lib.y3_loss_workspace_bytes()) // 4 + 4, dtype=torch.float32, device=dev)
+        self.loss_calls = []
+        for f, g in zip(self.fms, self.gt):
+            f.grad = self._new(N, f.h, f.w, D, Dld, zero=True)
+            self.loss_calls.append((lib.y3_loss_fwd_bwd, (f.v, g.data_ptr(), mdl.anchors_c, A, K, H, W, float(mdl.global_batch_size),
+                                                          self.loss4.data_ptr(), f.grad.v, self.loss_ws.data_ptr())))
+            f.gw = True
+        if tr:
+            self._build_backward()
+
+    # -- backward emission -------------------------------------------------------
+    def _grad_of(self, t):
+        """Gradient twin of activation t (allocated on first use; slices of a
+        concat buffer get slices of the concat's gradient)."""
+        if t.grad is None:
+            if t.parent is not None:
+                self._grad_of(t.parent)
+                return t.grad
+            t.grad = self._new(t.n, t.h, t.w, t.c, t.ld)
+            for ch in t.children:
+                ch.grad = _T(t.grad.buf, ch.n, ch.h, ch.w, ch.c, ch.ld, ch.off)
+        return t.grad
+
+    def _build_backward(self):
+        mdl = self.model
+        specs = mdl.specs
+        G = mdl.grads
+        Wt = mdl.params_t
+        N = self.n
+
+        def gptr(off):
+            return G.data_ptr() + 4 * off
+
+        # concat parents own the gradient storage of their slices
+        wg_need = 0
+        for op in self.ops:
+            if op[0] in ('conv_layer', 'head'):
+                sp = specs[op[1]]
+                src = op[2]
+                dd = op[3]
+                need = lib.y3_conv2d_wgrad_workspace(src.v, view(self.dz, dd.n, dd.h, dd.w, sp.cout), sp.k, sp.s)
+                wg_need = max(wg_need, int(need))
+        self.wg_ws = torch.empty(max(wg_need // 4, 4), dtype=torch.float32, device=mdl.device)
+        self.wg_ws_bytes = wg_need
+
+        first_src = self.x0
+        for op in reversed(self.ops):
+            kind = op[0]
+            if kind == 'head':
+                _, i, src, fm = op
+                sp = specs[i]
+                dfm = fm.grad
+                self._emit(self.bwd, lib.y3_colsum, dfm.v, gptr(sp.b_off))
+                self._emit(self.bwd, lib.y3_conv2d_wgrad, src.v, dfm.v, 1, 1, gptr(sp.w_off), self.wg_ws.data_ptr(), self.wg_ws_bytes)
+                ds = self._grad_of(src)
+                self._emit(self.bwd, lib.y3_conv2d_dgrad, dfm.v, Wt.data_ptr() + 4 * sp.w_off, 1, 1, ds.v, EPI_ACCUM if src.gw else 0)
+                src.mark_written()
+                self.bwd.append(('layer_done', i))
+            elif kind == 'upsample':
+                _, src, dst = op
+                assert dst.gw and not src.gw
+                ds = self._grad_of(src)
+                self._emit(self.bwd, lib.y3_upsample_sum2x_bwd, dst.grad.v, ds.v)
+                src.mark_written()
+            else:
+                _, i, src, a, y, resid, (smean, srstd, coef) = op
+                sp = specs[i]
+                assert y.gw, 'gradient of layer %d output never produced' % i
+                dy = y.grad
+                if resid is not None:                       # out = resid + y  ->  d resid += d out
+                    dr = self._grad_of(resid)
+                    self._emit(self.bwd, lib.y3_add_inplace if resid.gw else lib.y3_copy, dy.v, dr.v)
+                    resid.mark_written()
+                dz = _T(self.dz, a.n, a.h, a.w, sp.cout)
+                self._emit(self.bwd, lib.y3_bn_bwd_reduce, dy.v, a.v, smean, srstd, LRELU_ALPHA, self.bnb_ws.data_ptr(), None)
+                self._emit(self.bwd, lib.y3_bn_bwd_finalize, self.bnb_ws.data_ptr(), lib.y3_bn_bwd_partials(a.m, sp.cout), sp.cout, a.m,
+                           mdl.params.data_ptr() + 4 * sp.g_off, smean, srstd, LRELU_ALPHA, gptr(sp.g_off), gptr(sp.be_off), gptr(sp.b_off), coef)
+                self._emit(self.bwd, lib.y3_bn_bwd_apply, dy.v, a.v, coef, LRELU_ALPHA, dz.v)
+                self._emit(self.bwd, lib.y3_conv2d_wgrad, src.v, dz.v, sp.k, sp.s, gptr(sp.w_off), self.wg_ws.data_ptr(), self.wg_ws_bytes)
+                if src is not first_src:
+                    ds = self._grad_of(src)
+                    self._emit(self.bwd, lib.y3_conv2d_dgrad, dz.v, Wt.data_ptr() + 4 * sp.w_off, sp.k, sp.s, ds.v, EPI_ACCUM if src.gw else 0)
+                    src.mark_written()
+                self.bwd.append(('layer_done', i))
+
+    # -- execution -------------------------------------------------------------------
+    @staticmethod
+    def _run(lst, stream, hook=None):
+        for fn, args in lst:
+            if fn == 'layer_done':
+                if hook is not None:
+                    hook(args)
+                continue
+            rc = fn(*args, stream)
+            if rc != 0:
+                check(rc, fn.__name__)
+
+    def run_forward(self, stream):
+        self._run(self.fwd, stream)
+
+    def run_decode(self, stream):
+        fn, args = self.decode_call
+        check(fn(*args, stream), 'y3_decode_fwd')
+
+    def run_loss(self, stream):
+        self.loss4.zero_()
+        for fn, args in self.loss_calls:
+            check(fn(*args, stream), 'y3_loss_fwd_bwd')
+
+    def run_backward(self, stream, hook=None):
+        self._run(self.bwd, stream, hook)
+
+
+class _CallableModel:
+    """What get_keras_model()/get_keras_feature_map_model() hand out: callable
+    like a Keras model, ``m(batch, training=False)`` (inference.py:58)."""
+
+    def __init__(self, yolo, feature_maps):
+        self._y = yolo
+        self._fm = feature_maps
+
+    def __call__(self, batch, training=False):
+        if self._fm:
+            return self._y.feature_maps(batch, training=training)
+        return self._y.predict(batch)
+
+    @property
+    def trainable_weights(self):
+        return self._y.trainable_weights()
+
+
+class YoloV3:
+    # Constants controlling the network (model.py:22-26)
+    BLOCK_COUNT = 8
+    FILTER_COUNT = 1024
+    KERNEL_SIZE = 3
+    NETWORK_DOWNSAMPLE_FACTOR = 32
+    WEIGHT_DECAY = 5e-4      # declared by the reference but never applied (Q9)
+
+    def __init__(self, global_batch_size, img_size, number_classes, anchors=None, learning_rate=1e-4, device=None, seed=None,
+                 use_graph=False):
+        if not torch.cuda.is_available():
+            raise RuntimeError('yolo3.model.YoloV3 needs an MI355X (HIP) device: there is no CPU path')
+        self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+        self.number_classes = int(number_classes)
+        self.learning_rate = float(learning_rate)
+        self.global_batch_size = global_batch_size
+        self.img_size = [int(v) for v in img_size]           # [H, W, C]  (model.py:428,440)
+        if self.img_size[0] % 32 or self.img_size[1] % 32:
+            raise ValueError('image size must be a multiple of %d' % YoloV3.NETWORK_DOWNSAMPLE_FACTOR)
+        self.score_threshold = 0.1                           # dead attributes kept (Q10)
+        self.iou_threshold = 0.5
+        self.anchors = [(32, 32), (128, 128), (256, 256)] if anchors is None else [tuple(a) for a in anchors]
+        self.number_anchors = len(self.anchors)
+        self.anchors_c = _hip.float_array([v for a in self.anchors for v in a])
+        H, W, C = self.img_size
+        f = YoloV3.NETWORK_DOWNSAMPLE_FACTOR
+        self.box_count_fm1 = (H / f) * (W / f)
+        self.box_count_fm2 = (H / (f / 2)) * (W / (f / 2))
+        self.box_count_fm3 = (H / (f / 4)) * (W / (f / 4))
+        self.number_output_boxes = self.number_anchors * (self.box_count_fm1 + self.box_count_fm2 + self.box_count_fm3)
+        self.output_shape = [self.number_output_boxes, 5 + self.number_classes]
+
+        self.specs, self.arena_floats, chan_floats, self.moving_stride = build_layer_specs(C, self.number_anchors, self.number_classes)
+        dev = self.device
+        z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+        self.params = z(self.arena_floats)        # trainable arena: [W | b | gamma | beta] per layer
+        self.params_t = z(self.arena_floats)      # kernels with channel axes swapped (dgrad operand)
+        self.grads = z(self.arena_floats)
+        self.adam_m = z(self.arena_floats)
+        self.adam_v = z(self.arena_floats)
+        self.moving = z(2 * self.moving_stride)   # [moving_mean | moving_var]
+        self.chan = z(chan_floats)                # per BN layer: scale | shift | save_mean | save_rstd | k1 | k2 | k3
+        self.lr_t_dev = z(1)
+        self.beta1, self.beta2, self.adam_eps = 0.9, 0.999, 1e-7   # Keras Adam defaults (App. C5)
+        self.iterations = 0
+        self.use_graph = bool(use_graph)
+        self.dist = None                          # set by parallel.DataParallel.attach()
+        self._plans = {}
+        self._init_weights(seed)
+        self.model = _CallableModel(self, False)
+        self.model_feature_maps = _CallableModel(self, True)
+        self.optimizer = self
+
+    # ---- construction helpers --------------------------------------------------
+    def _init_weights(self, seed):
+        """Keras defaults: Glorot-uniform kernels, zero bias, gamma 1, beta 0,
+        moving mean 0 / variance 1 (App. C2, C4)."""
+        rng = np.random.default_rng(seed)
+        layers = []
+        for sp in self.specs:
+            limit = math.sqrt(6.0 / (sp.k * sp.k * sp.cin + sp.k * sp.k * sp.cout))
+            d = dict(W=rng.uniform(-limit, limit, (sp.k, sp.k, sp.cin, sp.cout)).astype(np.float32), b=np.zeros(sp.cout, np.float32))
+            if sp.bn:
+                d.update(gamma=np.ones(sp.cout, np.float32), beta=np.zeros(sp.cout, np.float32), mean=np.zeros(sp.cout, np.float32),
+                         var=np.ones(sp.cout, np.float32))
+            layers.append(d)
+        self.set_weights(layers)
+
+    # ---- weights in / out (Keras shapes, true Cin) --------------------------------------
+    def set_weights(self, layers):
+        """layers: list (creation order) of dicts W[kh,kw,Cin,Cout], b, and for
+        conv_layers gamma, beta, mean, var."""
+        assert len(layers) == len(self.specs)
+        host = np.zeros(self.arena_floats, np.float32)
+        mov = np.zeros(2 * self.moving_stride, np.float32)
+        mov[self.moving_stride:] = 1.0
+        for sp, d in zip(self.specs, layers):
+            Wk = np.asarray(d['W'], np.float32)
+            assert Wk.shape == (sp.k, sp.k, sp.cin, sp.cout), (Wk.shape, (sp.k, sp.k, sp.cin, sp.cout))
+            Wp = np.zeros((sp.k, sp.k, sp.cin_pad, sp.cout), np.float32)
+            Wp[:, :, :sp.cin, :] = Wk
+            host[sp.w_off:sp.w_off + Wp.size] = Wp.ravel()
+            host[sp.b_off:sp.b_off + sp.cout] = np.asarray(d['b'], np.float32)
+            if sp.bn:
+                host[sp.g_off:sp.g_off + sp.cout] = np.asarray(d['gamma'], np.float32)
+                host[sp.be_off:sp.be_off + sp.cout] = np.asarray(d['beta'], np.float32)
+                mov[sp.mv_off:sp.mv_off + sp.cout] = np.asarray(d['mean'], np.float32)
+                mov[self.moving_stride + sp.mv_off:self.moving_stride + sp.mv_off + sp.cout] = np.asarray(d['var'], np.float32)
+        self.params.copy_(torch.from_numpy(host))
+        self.moving.copy_(torch.from_numpy(mov))
+        self._refresh_transposed()
+
+    def _unpack(self, arena):
+        host = arena.detach().cpu().numpy()
+        out = []
+        for sp in self.specs:
+            Wp = host[sp.w_off:sp.w_off + sp.k * sp.k * sp.cin_pad * sp.cout].reshape(sp.k, sp.k, sp.cin_pad, sp.cout)
+            d = dict(W=Wp[:, :, :sp.cin, :].copy(), b=host[sp.b_off:sp.b_off + sp.cout].copy())
+            if sp.bn:
+                d['gamma'] = host[sp.g_off:sp.g_off + sp.cout].copy()
+                d['beta'] = host[sp.be_off:sp.be_off + sp.cout].copy()
+            out.append(d)
+        return out
+
+    def get_weights(self):
+        out = self._unpack(self.params)
+        mov = self.moving.detach().cpu().numpy()
+        for sp, d in zip(self.specs, out):
+            if sp.bn:
+                d['mean'] = mov[sp.mv_off:sp.mv_off + sp.cout].copy()
+                d['var'] = mov[self.moving_stride + sp.mv_off:self.moving_stride + sp.mv_off + sp.cout].copy()
+        return out
+
+    def get_gradients(self):
+        """Last step's gradients, same structure as get_weights() (W, b, gamma, beta)."""
+        return self._unpack(self.grads)
+
+    def trainable_weights(self):
+        """Flat list of arrays in Keras trainable_weights order (model.py:496)."""
+        out = []
+        for sp, d in zip(self.specs, self._unpack(self.params)):
+            out += [d['W'], d['b']] + ([d['gamma'], d['beta']] if sp.bn else [])
+        return out
+
+    def save_weights(self, path):
+        """Own weight file (the reference's TF checkpoint / SavedModel formats need TF)."""
+        flat = {}
+        for i, d in enumerate(self.get_weights()):
+            for k, v in d.items():
+                flat['l%03d_%s' % (i, k)] = v
+        flat['meta_img_size'] = np.asarray(self.img_size, np.int64)
+        flat['meta_number_classes'] = np.asarray(self.number_classes, np.int64)
+        flat['meta_anchors'] = np.asarray(self.anchors, np.float32)
+        flat['meta_global_batch_size'] = np.asarray(self.global_batch_size, np.int64)
+        flat['meta_learning_rate'] = np.asarray(self.learning_rate, np.float64)
+        flat['opt_iterations'] = np.asarray(self.iterations, np.int64)
+        flat['opt_m'] = self.adam_m.detach().cpu().numpy()
+        flat['opt_v'] = self.adam_v.detach().cpu().numpy()
+        np.savez(path, **flat)
+
+    def load_weights(self, path, load_optimizer=False):
+        z = np.load(path, allow_pickle=False)
+        layers = []
+        for i, sp in enumerate(self.specs):
+            d = {k: z['l%03d_%s' % (i, k)] for k in (['W', 'b', 'gamma', 'beta', 'mean', 'var'] if sp.bn else ['W', 'b'])}
+            layers.append(d)
+        self.set_weights(layers)
+        if load_optimizer and 'opt_m' in z:
+            self.adam_m.copy_(torch.from_numpy(z['opt_m']))
+            self.adam_v.copy_(torch.from_numpy(z['opt_v']))
+            self.iterations = int(z['opt_iterations'])
+
+    @staticmethod
+    def from_file(path, device=None):
+        z = np.load(path, allow_pickle=False)
+        y = YoloV3(int(z['meta_global_batch_size']), [int(v) for v in z['meta_img_size']], int(z['meta_number_classes']),
+                   [tuple(float(v) for v in a) for a in z['meta_anchors']], float(z['meta_learning_rate']), device=device)
+        y.load_weights(path)
+        return y
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _refresh_transposed(self):
+        st = self._stream()
+        for sp in self.specs[1:]:
+            check(lib.y3_transpose_weights(self.params.data_ptr() + 4 * sp.w_off, self.params_t.data_ptr() + 4 * sp.w_off, sp.k * sp.k,
+                                           sp.cin_pad, sp.cout, st), 'y3_transpose_weights')
+
+    # ---- reference API (model.py:466-479) ---------------------------------------------
+    def get_keras_model(self):
+        return self.model
+
+    def get_keras_feature_map_model(self):
+        return self.model_feature_maps
+
+    def get_optimizer(self):
+        return self.optimizer
+
+    def set_learning_rate(self, learning_rate):
+        self.learning_rate = float(learning_rate)
+
+    def get_learning_rate(self):
+        return self.learning_rate
+
+    # ---- execution -------------------------------------------------------------------------
+    def _plan(self, n, training):
+        key = (int(n), bool(training))
+        if key not in self._plans:
+            self._plans[key] = _Plan(self, int(n), bool(training))
+        return self._plans[key]
+
+    def _load_inputs(self, plan, images, gt_data=None):
+        images = torch.as_tensor(images)
+        if tuple(images.shape[1:]) != (self.img_size[2], self.img_size[0], self.img_size[1]):
+            raise ValueError('input shape %s does not match the model input (C,H,W)=%s (Q18: fixed at construction)'
+                             % (tuple(images.shape), (self.img_size[2], self.img_size[0], self.img_size[1])))
+        plan.in_nchw.copy_(images.to(torch.float32), non_blocking=True)
+        if gt_data is not None:
+            for dst, src in zip(plan.gt, gt_data):
+                dst.copy_(torch.as_tensor(src).to(torch.float32).reshape(dst.shape), non_blocking=True)
+
+    def predict(self, images):
+        """The saved 'yolov3' model (model.py:463): NCHW in -> [N, Nb, 5+K]."""
+        n = int(images.shape[0])
+        plan = self._plan(n, False)
+        self._load_inputs(plan, images)
+        st = self._stream()
+        plan.run_forward(st)
+        plan.run_decode(st)
+        return plan.boxes
+
+    def feature_maps(self, images, training=False):
+        """The 'yolov3_fm' model (model.py:462): three NCHW feature maps."""
+        n = int(images.shape[0])
+        plan = self._plan(n, training)
+        self._load_inputs(plan, images)
+        st = self._stream()
+        plan.run_forward(st)
+        return self._export_fms(plan, st)
+
+    def _export_fms(self, plan, st):
+        out = []
+        for f in plan.fms:
+            t = torch.empty(f.n, f.c, f.h, f.w, dtype=torch.float32, device=self.device)
+            check(lib.y3_nhwc_to_nchw(f.v, t.data_ptr(), st), 'y3_nhwc_to_nchw')
+            out.append(t)
+        return out
+
+    def _lr_t(self):
+        t = self.iterations
+        return self.learning_rate * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+
+    def _fwd_bwd(self, plan, st):
+        plan.run_forward(st)
+        plan.run_loss(st)
+        hook = self.dist.on_layer_done if self.dist is not None else None
+        if self.dist is not None:
+            self.dist.begin_step()
+        plan.run_backward(st, hook)
+
+    def _adam(self, st):
+        check(lib.y3_adam_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
+                               self.arena_floats, self.lr_t_dev.data_ptr(), self.beta1, self.beta2, self.adam_eps, st), 'y3_adam_step')
+        self._refresh_transposed()
+
+    def train_step(self, inputs):
+        """model.py:481-508 for this replica.  inputs = (images, (gt1, gt2, gt3),
+        loss_metric, loss_xy_metric, loss_wh_metric, loss_obj_metric, loss_class_metric);
+        metrics may be None.  Returns the loss value as a 0-d device tensor."""
+        images, gt_data = inputs[0], inputs[1]
+        metrics = list(inputs[2:]) + [None] * 5
+        n = int(images.shape[0])
+        plan = self._plan(n, True)
+        self._load_inputs(plan, images, gt_data)
+        self.iterations += 1
+        self.lr_t_dev.fill_(self._lr_t())
+        st = self._stream()
+        if self.use_graph and self.dist is None:
+            if plan.graph is None:
+                self._capture(plan)
+            plan.graph.replay()
+        else:
+            self._fwd_bwd(plan, st)
+            if self.dist is not None:
+                self.dist.finish_step()
+            self._adam(st)
+        parts = plan.loss4.clone()
+        loss_value = parts.sum() / float(self.global_batch_size)
+        for mtr, val in zip(metrics[:5], [loss_value, parts[0], parts[1], parts[2], parts[3]]):
+            if mtr is not None:
+                mtr.update_state(val)
+        return loss_value
+
+    def _capture(self, plan):
+        """Capture forward + loss + backward + Adam of one step into a HIP graph.
+        A warm-up pass (no Adam) runs first so lazy initialisation happens
+        outside the capture; it only touches scratch state plus the BN moving
+        statistics, which are restored before capturing."""
+        moving = self.moving.clone()
+        st = self._stream()
+        plan.run_forward(st)
+        plan.run_loss(st)
+        plan.run_backward(st)
+        self.moving.copy_(moving)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            st = self._stream()
+            plan.run_forward(st)
+            plan.run_loss(st)
+            plan.run_backward(st)
+            self._adam(st)
+        plan.graph = g
+
+    def dist_train_step(self, dist_strategy, inputs):
+        """model.py:510-515: per-replica step + SUM of the per-replica losses."""
+        if dist_strategy is not None and self.dist is None:
+            dist_strategy.attach(self)
+        loss = self.train_step(inputs)
+        return dist_strategy.reduce_sum(loss) if dist_strategy is not None else loss
+
+    def test_step(self, inputs):
+        """model.py:517-534: BN in inference mode, loss + metrics, no update."""
+        images, gt_data = inputs[0], inputs[1]
+        metrics = list(inputs[2:]) + [None] * 5
+        n = int(images.shape[0])
+        plan = self._plan(n, False)
+        self._load_inputs(plan, images, gt_data)
+        st = self._stream()
+        plan.run_forward(st)
+        plan.run_loss(st)
+        parts = plan.loss4.clone()
+        loss_value = parts.sum() / float(self.global_batch_size)
+        for mtr, val in zip(metrics[:5], [loss_value, parts[0], parts[1], parts[2], parts[3]]):
+            if mtr is not None:
+                mtr.update_state(val)
+        return loss_value
+
+    def dist_test_step(self, dist_strategy, inputs):
+        """model.py:536-540."""
+        loss = self.test_step(inputs)
+        return dist_strategy.reduce_sum(loss) if dist_strategy is not None else loss

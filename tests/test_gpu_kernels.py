@@ -1,0 +1,476 @@
+"""GPU parity of every HIP kernel, called through the C ABI (libyolo3hip.so),
+against plain torch-CPU fp32/fp64 references of the same op and against the
+oracle / golden fixtures.  Tolerances are stated per test."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from yolo3 import _hip
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    return _hip
+
+
+def _pad_same(x, k, s):
+    from oracle.model import same_pad
+    ph, pw = same_pad(x.shape[2], k, s), same_pad(x.shape[3], k, s)
+    return F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
+
+
+def _conv_ref(x, w_k, b, k, s, dtype=torch.float64):
+    """x NCHW, w_k Keras [kh,kw,ci,co] -> NCHW, TF SAME padding, in fp64."""
+    xx = _pad_same(x.to(dtype), k, s)
+    return F.conv2d(xx, w_k.to(dtype).permute(3, 2, 0, 1), None if b is None else b.to(dtype), stride=s)
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, s
+    (2, 13, 13, 64, 128, 3, 1),
+    (2, 13, 13, 128, 64, 1, 1),
+    (2, 26, 26, 32, 64, 3, 2),
+    (1, 13, 15, 32, 64, 3, 2),      # odd sizes: SAME pad_before = 1
+    (2, 32, 32, 4, 32, 3, 1),       # first layer (channels padded 3 -> 4)
+    (2, 13, 13, 256, 14, 1, 1),     # detection head, Cout not a multiple of 4
+    (2, 128, 128, 32, 128, 3, 1),   # 256 tiles of 128x128
+    (1, 64, 64, 64, 32, 1, 1),      # BN=32 tile
+    (3, 20, 20, 64, 64, 3, 1),      # BN=64 tile, M not a tile multiple
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd(hip, case):
+    """y3_conv2d_fwd vs fp64 conv2d; tolerance 2e-5 * max|ref| (fp32 fmaf chain over K <= 1152)."""
+    from util import nhwc_buf, stream, assert_close
+    n, h, w, cin, cout, k, s = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(n, cin, h, w, generator=g)
+    if cin == 4:
+        x[:, 3] = 0
+    wk = torch.randn(k, k, cin, cout, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    oh, ow = -(-h // s), -(-w // s)
+    sbuf, sv = nhwc_buf(n, h, w, cin, ld=cin + 8, off=4)
+    sv.copy_(x.permute(0, 2, 3, 1))
+    old = (cout + 3) // 4 * 4 + 4
+    dbuf, dv = nhwc_buf(n, oh, ow, cout, ld=old)
+    wd, bd = wk.contiguous().cuda(), b.cuda()
+    src = hip.Tensor(sv.data_ptr(), n, h, w, cin, cin + 8)
+    dst = hip.Tensor(dv.data_ptr(), n, oh, ow, cout, old)
+    tiles = hip.lib.y3_conv2d_stats_tiles(n * oh * ow, cout)
+    stats = torch.full((tiles * 2 * cout,), float('nan'), device='cuda')
+    hip.check(hip.lib.y3_conv2d_fwd(src, wd.data_ptr(), bd.data_ptr(), k, s, dst, hip.EPI_LRELU, 0.2, None, None, None, stats.data_ptr(), stream()))
+    ref = F.leaky_relu(_conv_ref(x, wk, b, k, s), 0.2)
+    assert_close(dv.cpu().permute(0, 3, 1, 2), ref, rtol=2e-5, what='conv fwd')
+    st = stats.view(tiles, 2, cout).double().sum(0).cpu()
+    assert_close(st[0], ref.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-4 * float(ref.abs().sum(dim=(0, 2, 3)).max()), what='stats sum')
+    assert_close(st[1], (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-4, what='stats sumsq')
+    # pitch padding untouched
+    if old > cout:
+        assert torch.isnan(dbuf.view(-1, old)[:, cout:]).all()
+
+
+def test_conv_fwd_fused_inference_epilogue(hip):
+    """lrelu -> scale/shift -> + resid (inference-mode BN folded, model.py:38,47)."""
+    from util import nhwc_buf, stream, assert_close
+    n, h, w, cin, cout, k, s = 2, 26, 26, 64, 128, 3, 1
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wk = torch.randn(k, k, cin, cout, generator=g) * 0.05
+    b = torch.randn(cout, generator=g)
+    sc = torch.rand(cout, generator=g) + 0.5
+    sh = torch.randn(cout, generator=g)
+    r = torch.randn(n, cout, h, w, generator=g)
+    _, sv = nhwc_buf(n, h, w, cin)
+    sv.copy_(x.permute(0, 2, 3, 1))
+    _, rv = nhwc_buf(n, h, w, cout, ld=2 * cout, off=cout)
+    rv.copy_(r.permute(0, 2, 3, 1))
+    _, dv = nhwc_buf(n, h, w, cout)
+    wd, bd, scd, shd = wk.contiguous().cuda(), b.cuda(), sc.cuda(), sh.cuda()
+    hip.check(hip.lib.y3_conv2d_fwd(hip.Tensor(sv.data_ptr(), n, h, w, cin, cin), wd.data_ptr(), bd.data_ptr(), k, s,
+                                    hip.Tensor(dv.data_ptr(), n, h, w, cout, cout), hip.EPI_LRELU, 0.2, scd.data_ptr(), shd.data_ptr(),
+                                    hip.Tensor(rv.data_ptr(), n, h, w, cout, 2 * cout), None, stream()))
+    ref = F.leaky_relu(_conv_ref(x, wk, b, k, s), 0.2) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None] + r.double()
+    assert_close(dv.cpu().permute(0, 3, 1, 2), ref, rtol=2e-5, what='fused epilogue')
+
+
+DGRAD_CASES = [
+    (2, 13, 13, 64, 128, 3, 1),
+    (2, 13, 13, 128, 64, 1, 1),
+    (2, 26, 26, 32, 64, 3, 2),
+    (1, 13, 15, 32, 64, 3, 2),
+    (2, 13, 13, 256, 14, 1, 1),
+    (2, 64, 64, 64, 128, 3, 2),
+]
+
+
+@pytest.mark.parametrize('case', DGRAD_CASES)
+@pytest.mark.parametrize('accum', [False, True])
+def test_conv_dgrad(hip, case, accum):
+    """y3_conv2d_dgrad vs autograd of the fp64 conv; 2e-5 * max|ref|."""
+    from util import nhwc_buf, stream, assert_close
+    n, h, w, cin, cout, k, s = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    wk = torch.randn(k, k, cin, cout, generator=g) * 0.1
+    y = _conv_ref(x, wk, None, k, s)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    oh, ow = y.shape[2], y.shape[3]
+    cld = (cout + 3) // 4 * 4
+    _, ddv = nhwc_buf(n, oh, ow, cout, ld=cld, fill=float('nan'))
+    ddv.copy_(dy.permute(0, 2, 3, 1))
+    _, dsv = nhwc_buf(n, h, w, cin, ld=cin + 4, fill=0.0)
+    init = torch.randn(n, h, w, cin, generator=g)
+    if accum:
+        dsv.copy_(init)
+    wt = wk.permute(0, 1, 3, 2).contiguous().cuda()          # [kh,kw,co,ci]
+    # also exercise y3_transpose_weights
+    wt2 = torch.empty_like(wt)
+    wd = wk.contiguous().cuda()
+    hip.check(hip.lib.y3_transpose_weights(wd.data_ptr(), wt2.data_ptr(), k * k, cin, cout, stream()))
+    assert torch.equal(wt, wt2)
+    hip.check(hip.lib.y3_conv2d_dgrad(hip.Tensor(ddv.data_ptr(), n, oh, ow, cout, cld), wt2.data_ptr(), k, s,
+                                      hip.Tensor(dsv.data_ptr(), n, h, w, cin, cin + 4), hip.EPI_ACCUM if accum else 0, stream()))
+    ref = x.grad.permute(0, 2, 3, 1)
+    if accum:
+        ref = ref + init.double()
+    assert_close(dsv.cpu(), ref, rtol=2e-5, what='dgrad')
+
+
+WGRAD_CASES = CONV_CASES[:6] + [(8, 52, 52, 128, 256, 1, 1), (2, 64, 64, 32, 64, 3, 2)]
+
+
+@pytest.mark.parametrize('case', WGRAD_CASES)
+def test_conv_wgrad(hip, case):
+    """y3_conv2d_wgrad vs autograd; 5e-5 * max|ref| (fp32 sums over up to 21k pixels, fp32 slab combine)."""
+    from util import nhwc_buf, stream, assert_close
+    n, h, w, cin, cout, k, s = case
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wk = (torch.randn(k, k, cin, cout, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    xx = _pad_same(x.double(), k, s)
+    y = F.conv2d(xx, wk.permute(3, 2, 0, 1), None, stride=s)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    oh, ow = y.shape[2], y.shape[3]
+    cld = (cout + 3) // 4 * 4
+    _, sv = nhwc_buf(n, h, w, cin, ld=cin + 4)
+    sv.copy_(x.permute(0, 2, 3, 1))
+    _, ddv = nhwc_buf(n, oh, ow, cout, ld=cld, fill=0.0)
+    ddv.copy_(dy.permute(0, 2, 3, 1))
+    src = hip.Tensor(sv.data_ptr(), n, h, w, cin, cin + 4)
+    dd = hip.Tensor(ddv.data_ptr(), n, oh, ow, cout, cld)
+    wsb = int(hip.lib.y3_conv2d_wgrad_workspace(src, dd, k, s))
+    ws = torch.empty(wsb // 4 + 4, device='cuda')
+    dw = torch.full((k, k, cin, cout), float('nan'), device='cuda')
+    hip.check(hip.lib.y3_conv2d_wgrad(src, dd, k, s, dw.data_ptr(), ws.data_ptr(), wsb, stream()))
+    assert_close(dw.cpu(), wk.grad, rtol=5e-5, what='wgrad')
+
+
+@pytest.mark.parametrize('shape', [(2, 13, 13, 64), (8, 52, 52, 128), (1, 104, 104, 32), (2, 7, 9, 1024)])
+def test_batchnorm_train_fwd_bwd(hip, shape):
+    """stats finalize + apply + backward (reduce / finalize / apply) vs fp64 autograd of BN(lrelu(z))."""
+    from util import nhwc_buf, stream, assert_close
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(17)
+    z = torch.randn(n, h, w, c, generator=g, dtype=torch.float64, requires_grad=True)
+    gamma = (torch.rand(c, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
+    beta = torch.randn(c, generator=g, dtype=torch.float64).requires_grad_(True)
+    resid = torch.randn(n, h, w, c, generator=g)
+    a = F.leaky_relu(z, 0.2)
+    mean = a.mean(dim=(0, 1, 2))
+    var = a.var(dim=(0, 1, 2), unbiased=False)
+    y = (a - mean) * torch.rsqrt(var + 1e-3) * gamma + beta + resid.double()
+    dy = torch.randn(n, h, w, c, generator=g)
+    y.backward(dy.double())
+    M = n * h * w
+    # forward: feed the conv epilogue's partial sums (here computed in torch) then finalize + apply
+    ad = a.detach().float().cuda().contiguous()
+    tiles = 7
+    chunks = torch.chunk(ad.view(M, c), tiles, dim=0)
+    tiles = len(chunks)
+    stats = torch.stack([torch.stack([ch.sum(0), (ch * ch).sum(0)]) for ch in chunks]).contiguous()
+    gd, bd = gamma.detach().float().cuda(), beta.detach().float().cuda()
+    mm, mv = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+    smean, srstd, scale, shift = (torch.empty(c, device='cuda') for _ in range(4))
+    hip.check(hip.lib.y3_bn_stats_finalize(stats.data_ptr(), tiles, c, M, gd.data_ptr(), bd.data_ptr(), 1e-3, 0.99, mm.data_ptr(), mv.data_ptr(),
+                                           smean.data_ptr(), srstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), stream()))
+    assert_close(smean.cpu(), mean.detach(), rtol=1e-5, atol=1e-6, what='batch mean')
+    assert_close(srstd.cpu(), torch.rsqrt(var.detach() + 1e-3), rtol=1e-5, what='rstd')
+    assert_close(mm.cpu(), 0.01 * mean.detach(), rtol=1e-5, atol=1e-7, what='moving mean')
+    assert_close(mv.cpu(), 0.99 + 0.01 * var.detach() * M / (M - 1), rtol=1e-5, what='moving var')
+    _, rv = nhwc_buf(n, h, w, c)
+    rv.copy_(resid)
+    _, yv = nhwc_buf(n, h, w, c, ld=c + 8)
+    A = hip.Tensor(ad.data_ptr(), n, h, w, c, c)
+    hip.check(hip.lib.y3_bn_apply(A, scale.data_ptr(), shift.data_ptr(), hip.Tensor(rv.data_ptr(), n, h, w, c, c),
+                                  hip.Tensor(yv.data_ptr(), n, h, w, c, c + 8), stream()))
+    assert_close(yv.cpu(), y.detach(), rtol=1e-5, what='bn apply')
+    # backward
+    _, dyv = nhwc_buf(n, h, w, c, ld=c + 4)
+    dyv.copy_(dy)
+    DY = hip.Tensor(dyv.data_ptr(), n, h, w, c, c + 4)
+    parts = hip.lib.y3_bn_bwd_partials(M, c)
+    pws = torch.empty(parts * 5 * c, device='cuda')
+    npart = C.c_int(0)
+    hip.check(hip.lib.y3_bn_bwd_reduce(DY, A, smean.data_ptr(), srstd.data_ptr(), 0.2, pws.data_ptr(), C.byref(npart), stream()))
+    assert npart.value == parts
+    dg, db, dbias, coef = torch.empty(c, device='cuda'), torch.empty(c, device='cuda'), torch.empty(c, device='cuda'), torch.empty(3 * c, device='cuda')
+    hip.check(hip.lib.y3_bn_bwd_finalize(pws.data_ptr(), parts, c, M, gd.data_ptr(), smean.data_ptr(), srstd.data_ptr(), 0.2, dg.data_ptr(),
+                                         db.data_ptr(), dbias.data_ptr(), coef.data_ptr(), stream()))
+    _, dzv = nhwc_buf(n, h, w, c)
+    hip.check(hip.lib.y3_bn_bwd_apply(DY, A, coef.data_ptr(), 0.2, hip.Tensor(dzv.data_ptr(), n, h, w, c, c), stream()))
+    assert_close(dg.cpu(), gamma.grad, rtol=1e-4, what='dgamma')
+    assert_close(db.cpu(), beta.grad, rtol=1e-4, what='dbeta')
+    assert_close(dzv.cpu(), z.grad, rtol=1e-4, what='dz')
+    assert_close(dbias.cpu(), z.grad.sum(dim=(0, 1, 2)), rtol=1e-4, atol=1e-4 * float(z.grad.abs().sum(dim=(0, 1, 2)).max()), what='dbias')
+
+
+def test_bn_fold_inference(hip):
+    from util import stream, assert_close
+    c = 96
+    g = torch.Generator().manual_seed(3)
+    ga, be, mu = (torch.randn(c, generator=g) for _ in range(3))
+    va = torch.rand(c, generator=g) + 0.1
+    d = [t.cuda() for t in (ga, be, mu, va)]
+    sc, sh = torch.empty(c, device='cuda'), torch.empty(c, device='cuda')
+    hip.check(hip.lib.y3_bn_fold_inference(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 1e-3, c, sc.data_ptr(), sh.data_ptr(), stream()))
+    rs = ga.double() / torch.sqrt(va.double() + 1e-3)
+    assert_close(sc.cpu(), rs, rtol=1e-6)
+    assert_close(sh.cpu(), be.double() - mu.double() * rs, rtol=1e-6)
+
+
+def test_upsample_sum2x(hip):
+    """All-ones Conv2DTranspose (Q3) forward / backward vs the literal conv_transpose2d."""
+    from util import nhwc_buf, stream, assert_close
+    n, h, w, c = 2, 5, 7, 64
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(n, c, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.conv_transpose2d(x, torch.ones(c, c, 2, 2, dtype=torch.float64), stride=2)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    _, xv = nhwc_buf(n, h, w, c)
+    xv.copy_(x.detach().permute(0, 2, 3, 1))
+    _, ov = nhwc_buf(n, 2 * h, 2 * w, c, ld=2 * c)        # written into the first half of a concat buffer
+    hip.check(hip.lib.y3_upsample_sum2x_fwd(hip.Tensor(xv.data_ptr(), n, h, w, c, c), hip.Tensor(ov.data_ptr(), n, 2 * h, 2 * w, c, 2 * c), stream()))
+    assert_close(ov.cpu().permute(0, 3, 1, 2), y.detach(), rtol=1e-5, what='upsample fwd')
+    _, dov = nhwc_buf(n, 2 * h, 2 * w, c, ld=2 * c)
+    dov.copy_(dy.permute(0, 2, 3, 1))
+    _, dxv = nhwc_buf(n, h, w, c)
+    hip.check(hip.lib.y3_upsample_sum2x_bwd(hip.Tensor(dov.data_ptr(), n, 2 * h, 2 * w, c, 2 * c), hip.Tensor(dxv.data_ptr(), n, h, w, c, c), stream()))
+    assert_close(dxv.cpu().permute(0, 3, 1, 2), x.grad, rtol=1e-5, what='upsample bwd')
+
+
+def test_data_movement(hip):
+    from util import nhwc_buf, stream
+    n, h, w, c = 2, 6, 5, 3
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(n, c, h, w, generator=g).cuda()
+    _, dv = nhwc_buf(n, h, w, 4)
+    hip.check(hip.lib.y3_nchw_to_nhwc(x.data_ptr(), n, c, h, w, hip.Tensor(dv.data_ptr(), n, h, w, 4, 4), stream()))
+    assert torch.equal(dv[..., :3], x.permute(0, 2, 3, 1)) and (dv[..., 3] == 0).all()
+    back = torch.empty(n, 4, h, w, device='cuda')
+    hip.check(hip.lib.y3_nhwc_to_nchw(hip.Tensor(dv.data_ptr(), n, h, w, 4, 4), back.data_ptr(), stream()))
+    assert torch.equal(back[:, :3], x)
+    _, a = nhwc_buf(n, h, w, 8, ld=16, fill=1.0)
+    _, b = nhwc_buf(n, h, w, 8, ld=8, fill=2.0)
+    A, B = hip.Tensor(a.data_ptr(), n, h, w, 8, 16), hip.Tensor(b.data_ptr(), n, h, w, 8, 8)
+    hip.check(hip.lib.y3_add_inplace(A, B, stream()))
+    assert (b == 3.0).all()
+    hip.check(hip.lib.y3_copy(B, A, stream()))
+    assert (a == 3.0).all()
+    f = torch.empty(1001, device='cuda')
+    hip.check(hip.lib.y3_fill(f.data_ptr(), 1001, 2.5, stream()))
+    assert (f == 2.5).all()
+    _, m = nhwc_buf(2, 13, 13, 14, ld=16, fill=0.0)
+    vals = torch.randn(2, 13, 13, 14, generator=g)
+    m.copy_(vals)
+    out = torch.empty(14, device='cuda')
+    hip.check(hip.lib.y3_colsum(hip.Tensor(m.data_ptr(), 2, 13, 13, 14, 16), out.data_ptr(), stream()))
+    np.testing.assert_allclose(out.cpu().numpy(), vals.double().sum(dim=(0, 1, 2)).numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_errors_are_reported(hip):
+    """Bad arguments return an error code and a message; nothing is launched."""
+    t = hip.Tensor(0, 1, 1, 1, 4, 4)
+    rc = hip.lib.y3_conv2d_fwd(t, None, None, 3, 1, t, 0, 0.0, None, None, None, None, None)
+    assert rc == -1 and b'null' in hip.lib.y3_last_error()
+    with pytest.raises(hip.HipError):
+        hip.check(rc, 'y3_conv2d_fwd')
+
+
+def test_decode_matches_oracle(hip):
+    """y3_decode_fwd vs oracle.model.decode (fp64); 1e-5 relative to the box scale."""
+    from oracle import model as om
+    from util import nhwc_buf, stream, assert_close
+    n, A, K, H, W = 3, 2, 2, 416, 416
+    anchors = [(64, 384), (384, 64)]
+    g = torch.Generator().manual_seed(29)
+    fms = [torch.randn(n, A * (5 + K), H // s, W // s, generator=g) * 1.5 for s in (32, 16, 8)]
+    ref = om.decode([f.double() for f in fms], (H, W, 3), anchors, K)
+    views = []
+    arr = (hip.Tensor * 3)()
+    for i, f in enumerate(fms):
+        _, v = nhwc_buf(n, f.shape[2], f.shape[3], 14, ld=16)
+        v.copy_(f.permute(0, 2, 3, 1))
+        views.append(v)
+        arr[i] = hip.Tensor(v.data_ptr(), n, f.shape[2], f.shape[3], 14, 16)
+    nb = ref.shape[1]
+    out = torch.empty(n, nb, 5 + K, device='cuda')
+    hip.check(hip.lib.y3_decode_fwd(arr, 3, hip.float_array([v for a in anchors for v in a]), A, K, H, W, out.data_ptr(), stream()))
+    assert nb == 7098
+    assert_close(out.cpu()[..., :4], ref[..., :4], rtol=1e-5, what='boxes')
+    assert_close(out.cpu()[..., 4:], ref[..., 4:], rtol=1e-5, atol=2e-6, what='scores')
+
+
+def _labels(rng, n, img, anchors, K, per_image=3):
+    from yolo3.imagereader import format_boxes
+    labs = [[], [], []]
+    for _ in range(n):
+        k = rng.integers(0, per_image + 1)
+        wh = rng.integers(20, img // 2, (k, 2))
+        xy = np.stack([rng.integers(0, img - wh[:, 0]), rng.integers(0, img - wh[:, 1])], 1) if k else np.zeros((0, 2), int)
+        boxes = np.concatenate([xy, wh, rng.integers(0, K, (k, 1))], 1).astype(np.int32)
+        lab = format_boxes(boxes, (img, img, 3), anchors, K)
+        for i in range(3):
+            labs[i].append(lab[i])
+    return [np.stack(l) for l in labs]
+
+
+@pytest.mark.parametrize('empty', [False, True])
+def test_loss_fwd_bwd_matches_oracle(hip, empty):
+    """y3_loss_fwd_bwd vs oracle.model.loss_layer + autograd in fp64; losses 1e-5, gradients 1e-4 relative."""
+    from oracle import model as om
+    from util import nhwc_buf, stream, assert_close
+    n, A, K, img = 4, 2, 2, 416
+    anchors = [(64, 384), (384, 64)]
+    rng = np.random.default_rng(31)
+    gts = _labels(rng, n, img, anchors, K, per_image=0 if empty else 4)
+    g = torch.Generator().manual_seed(37)
+    loss4 = torch.zeros(4, device='cuda')
+    ws = torch.zeros(int(hip.lib.y3_loss_workspace_bytes()) // 4 + 4, device='cuda')
+    ref_parts = np.zeros(4)
+    gbs = 16.0
+    for si, s in enumerate((32, 16, 8)):
+        G = img // s
+        fm = (torch.randn(n, A * (5 + K), G, G, generator=g) * 1.2).double().requires_grad_(True)
+        gt = torch.from_numpy(gts[si])
+        # put one prediction near the origin so the ignore mask (Q7) actually fires somewhere
+        parts = om.loss_layer(fm, gt.double(), (img, img, 3), anchors, K)
+        total = sum(parts) / gbs
+        total.backward()
+        ref_parts += np.array([float(p) for p in parts])
+        _, fv = nhwc_buf(n, G, G, 14, ld=16, fill=0.0)
+        fv.copy_(fm.detach().float().permute(0, 2, 3, 1))
+        _, dv = nhwc_buf(n, G, G, 14, ld=16, fill=0.0)
+        gd = gt.float().cuda().contiguous()
+        hip.check(hip.lib.y3_loss_fwd_bwd(hip.Tensor(fv.data_ptr(), n, G, G, 14, 16), gd.data_ptr(), hip.float_array([v for a in anchors for v in a]),
+                                          A, K, img, img, gbs, loss4.data_ptr(), hip.Tensor(dv.data_ptr(), n, G, G, 14, 16), ws.data_ptr(), stream()))
+        assert_close(dv.cpu().permute(0, 3, 1, 2), fm.grad, rtol=1e-4, what='dfm scale %d' % s)
+    assert_close(loss4.cpu(), ref_parts, rtol=2e-5, what='loss parts (xy, wh, obj, class)')
+
+
+def test_adam_matches_oracle(hip):
+    """y3_adam_step vs oracle.model.AdamState (Keras form, eps outside the bias correction); 3 steps, 1e-6 relative."""
+    from oracle import model as om
+    from util import stream, assert_close
+    count = 100003
+    g = torch.Generator().manual_seed(41)
+    p0 = torch.randn(count, generator=g)
+    ref_p = p0.clone().double()
+    st = om.AdamState([ref_p], 1e-3)
+    p, m, v = p0.cuda(), torch.zeros(count, device='cuda'), torch.zeros(count, device='cuda')
+    lr = torch.zeros(1, device='cuda')
+    for _ in range(3):
+        gr = torch.randn(count, generator=g) * 0.01
+        st.step([ref_p], [gr.double()])
+        lr.fill_(st.lr_t())
+        gd = gr.cuda()
+        hip.check(hip.lib.y3_adam_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), count, lr.data_ptr(), 0.9, 0.999, 1e-7, stream()))
+    assert_close(p.cpu(), ref_p, rtol=1e-6, what='adam params')
+    assert_close(m.cpu(), st.m[0], rtol=1e-5, what='adam m')
+    assert_close(v.cpu(), st.v[0], rtol=1e-5, what='adam v')
+
+
+def _golden_nms(golden_dir):
+    return sorted(glob.glob(os.path.join(golden_dir, 'nms_*.npz')))
+
+
+def test_nms_matches_reference_goldens(hip, golden_dir):
+    """Class-wise NMS kernel vs the outputs of the reference's bbox_utils (tests/golden): keep indices,
+    labels and scores must be IDENTICAL (integer / bit-exact)."""
+    from yolo3 import bbox_utils
+    names = [p for p in _golden_nms(golden_dir) if 'units' not in p]
+    assert len(names) >= 8
+    for path in names:
+        z = np.load(path)
+        rows = torch.from_numpy(z['rows']).cuda()[None]
+        b, s, l, keep = bbox_utils.detect(rows, float(z['min_box']))[0]
+        if 'keep' not in z:
+            assert b is None, path
+            continue
+        assert np.array_equal(keep, z['keep']), path
+        assert np.array_equal(l, z['labels']), path
+        assert np.array_equal(s.view(np.uint32), z['scores'].view(np.uint32)), path
+        assert np.array_equal(b, z['boxes']), path
+
+
+def test_nms_batched_and_api(hip, golden_dir):
+    """Several images in one launch + the reference-signature wrappers."""
+    from yolo3 import bbox_utils
+    from oracle import nms as onms
+    za = np.load(os.path.join(golden_dir, 'nms_sparse416_k2.npz'))
+    zb = np.load(os.path.join(golden_dir, 'nms_dense416_k2.npz'))
+    rows = torch.from_numpy(np.stack([za['rows'], zb['rows'], za['rows']])).cuda()
+    res = bbox_utils.detect(rows, 32.0)
+    assert np.array_equal(res[0][3], za['keep']) and np.array_equal(res[1][3], zb['keep']) and np.array_equal(res[2][3], za['keep'])
+    f = onms.filter_small_boxes(za['rows'], 32)
+    b, s, l = bbox_utils.per_class_nms(f[:, 0:4], f[:, 4:5], f[:, 5:])
+    assert np.array_equal(b, za['boxes']) and np.array_equal(l, za['labels'])
+    u = np.load(os.path.join(golden_dir, 'nms_units.npz'))
+    for thr in (0.3, 0.5, 0.0):
+        assert bbox_utils.single_class_nms(u['boxes'], u['scores'], thr) == list(u['keep_%g' % thr]), thr
+
+
+def test_nms_clip_and_large(hip):
+    """clip-to-image option (inference.py:62-65 intent) and the > 16384-candidate global-memory path vs the oracle."""
+    from yolo3 import bbox_utils
+    from oracle import nms as onms
+    rng = np.random.default_rng(43)
+    nb = 20000
+    rows = np.zeros((nb, 6), np.float32)
+    c = rng.uniform(0, 800, (nb, 2))
+    wh = rng.uniform(20, 90, (nb, 2))
+    rows[:, 0:2] = c - wh / 2
+    rows[:, 2:4] = c + wh / 2
+    rows[:, 4] = rng.uniform(0.3, 1, nb)
+    rows[:, 5] = rng.uniform(0.3, 1, nb)
+    sc = np.sqrt(rows[:, 5] * rows[:, 4])
+    _, first = np.unique(sc, return_index=True)
+    rows = rows[np.sort(first)]            # drop score ties (argsort order unspecified in the reference)
+    clipped = rows.copy()
+    clipped[:, [0, 2]] = np.clip(clipped[:, [0, 2]], 0, 700)
+    clipped[:, [1, 3]] = np.clip(clipped[:, [1, 3]], 0, 750)
+    want = onms.detect_rows(clipped, 32)[0]
+    got = bbox_utils.detect(torch.from_numpy(rows).cuda()[None], 32.0, clip_wh=(700, 750))[0]
+    assert rows.shape[0] > 16384
+    assert np.array_equal(got[3], want)
+
+
+def test_zscore_matches_reference_goldens(hip, golden_dir):
+    """y3_zscore vs imagereader.zscore_normalize outputs; 2e-6 absolute on O(1) values."""
+    from yolo3 import imagereader
+    z = np.load(os.path.join(golden_dir, 'zscore.npz'))
+    for k in 'abc':
+        got = imagereader.zscore_normalize(z[k])
+        assert got.dtype == np.float32 and got.shape == z[k].shape
+        np.testing.assert_allclose(got, z[k + '_out'], rtol=2e-6, atol=2e-6)
