@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the YOLOv3 training step on MI355X.
+
+Workload (BASELINE.json metric): one ``train.py`` step = forward (training-mode
+BatchNorm) + loss + backward + Keras Adam (+ RCCL gradient all-reduce when
+N > 1), per-GPU batch 8, 416x416x3, anchors [(64,384),(384,64)], 2 classes,
+fp32, synthetic N(0,1) images / random labels / Glorot weights, all resident
+in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  ``roofline`` covers the dominant kernels (the
+MFMA implicit-GEMM conv family: forward, dgrad, wgrad): algorithmic conv FLOPs
+of one step / summed kernel time of those launches, timed with HIP events on
+the launch stream in an extra instrumented step.  ``cpu_baseline`` times the
+CPU oracle (torch-CPU restatement of the reference graph; TensorFlow is not
+available) on a bounded sample, rank 0 and N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'object-detection-yolov3_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+ANCHORS = [(64, 384), (384, 64)]
+K = 2
+IMG = 416
+BATCH = 8
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def conv_flops_per_image(specs, img):
+    """2*MAC of every conv layer: (fwd, train = fwd + dgrad + wgrad, no dgrad for conv1)."""
+    fwd = 0
+    first = 0
+    sizes = []
+    # replay the strides: spatial size of each layer's OUTPUT (creation order)
+    seq = [1, 2, 2, 2, 4] + [4] * 4 + [8] + [8] * 16 + [16] + [16] * 16 + [32] + [32] * 8
+    seq += [32] * 7 + [32] + [16] * 7 + [16] + [8] * 7
+    assert len(seq) == len(specs)
+    for i, (sp, st) in enumerate(zip(specs, seq)):
+        o = (img // st) ** 2
+        mac = o * sp.k * sp.k * sp.cin * sp.cout
+        fwd += 2 * mac
+        if i == 0:
+            first = 2 * mac
+        sizes.append(mac)
+    return fwd, 3 * fwd - first
+
+
+def synth_labels(rng, n):
+    from yolo3.imagereader import format_boxes
+    labs = [[], [], []]
+    for _ in range(n):
+        k = int(rng.integers(1, 5))
+        wh = rng.integers(40, 301, (k, 2))
+        xy = np.stack([rng.integers(0, IMG - wh[:, 0] + 1), rng.integers(0, IMG - wh[:, 1] + 1)], 1)
+        boxes = np.concatenate([xy, wh, rng.integers(0, K, (k, 1))], 1).astype(np.int32)
+        lab = format_boxes(boxes, (IMG, IMG, 3), ANCHORS, K)
+        for i in range(3):
+            labs[i].append(lab[i])
+    return [np.stack(l) for l in labs]
+
+
+def timed_conv_pass(yolo, plan):
+    """One eager step with a HIP-event pair around every MFMA conv launch.  Returns (seconds, per-entry dict)."""
+    from yolo3._hip import lib, check
+    conv_fns = {'y3_conv2d_fwd': 'conv2d_fwd', 'y3_conv2d_dgrad': 'conv2d_dgrad', 'y3_conv2d_wgrad': 'conv2d_wgrad'}
+    st = torch.cuda.current_stream().cuda_stream
+    pairs = []
+    for lst in (plan.fwd, None, plan.bwd):
+        if lst is None:
+            plan.run_loss(st)
+            continue
+        for fn, args in lst:
+            if fn == 'layer_done':
+                continue
+            name = conv_fns.get(getattr(fn, '__name__', ''))
+            if name:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                check(fn(*args, st), name)
+                b.record()
+                pairs.append((name, a, b))
+            else:
+                check(fn(*args, st), 'launch')
+    torch.cuda.synchronize()
+    per = {}
+    for name, a, b in pairs:
+        d = per.setdefault(name, [0.0, 0])
+        d[0] += a.elapsed_time(b) * 1e-3
+        d[1] += 1
+    return sum(v[0] for v in per.values()), per
+
+
+def cpu_baseline(seed, budget_s=25.0):
+    """The oracle's train step (torch-CPU fp32) on the same shapes; bounded sample."""
+    from oracle import model as om
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 16)))
+    cores = torch.get_num_threads()
+    params = om.init_params(3, len(ANCHORS), K, seed=seed)
+    rng = np.random.default_rng(seed)
+    g = torch.Generator().manual_seed(seed)
+    # probe with a small batch to size the sample
+    def run(bs, steps):
+        net = om.Net(params, 3, len(ANCHORS), K, dtype=torch.float32, requires_grad=True)
+        adam = om.AdamState(net.trainable(), 1e-4)
+        images = torch.randn(bs, 3, IMG, IMG, generator=g)
+        gts = [torch.from_numpy(x) for x in synth_labels(rng, bs)]
+        t0 = time.time()
+        for _ in range(steps):
+            om.train_step(net, adam, images, gts, (IMG, IMG, 3), ANCHORS, K, bs)
+        return time.time() - t0
+    t1 = run(1, 1)                    # includes first-touch overheads; only used to size the sample
+    bs = BATCH if t1 * BATCH <= budget_s else max(1, int(budget_s / max(t1, 1e-3)))
+    steps = 1
+    t = run(bs, steps)
+    return dict(value=bs * steps / t, unit='images/s', cores=cores, kind='port',
+                sample='oracle/model.py train_step (torch-CPU fp32 restatement of model.py:481-508; TensorFlow unavailable), '
+                       '%d step(s) at batch %d, 416x416, %.1f s' % (steps, bs, t))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying a HIP graph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--bucket-mb', type=float, default=32.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    from yolo3.model import YoloV3
+    strategy = None
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        from yolo3.parallel import DataParallel
+        strategy = DataParallel(bucket_mb=args.bucket_mb)
+
+    global_batch = BATCH * world
+    use_graph = (not args.no_graph) and world == 1
+    yolo = YoloV3(global_batch, [IMG, IMG, 3], K, ANCHORS, learning_rate=1e-4, seed=1, use_graph=use_graph)
+    if strategy is not None:
+        strategy.attach(yolo)
+        strategy.broadcast_parameters(yolo.params, yolo.moving)
+        yolo._refresh_transposed()
+    g = torch.Generator().manual_seed(100 + rank)
+    images = torch.randn(BATCH, 3, IMG, IMG, generator=g).cuda()
+    gts = [torch.from_numpy(x).cuda() for x in synth_labels(np.random.default_rng(3 + rank), BATCH)]
+    inputs = (images, gts)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = yolo.dist_train_step(strategy, inputs)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = yolo.dist_train_step(strategy, inputs)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss_val = float(loss) if loss is not None else float('nan')
+    if not np.isfinite(loss_val):
+        raise SystemExit('loss is not finite: %r' % loss_val)
+
+    # instrumented pass: HIP events around every conv launch (after the timed region)
+    fwd_fl, train_fl = conv_flops_per_image(yolo.specs, IMG)
+    plan = yolo._plan(BATCH, True)
+    conv_s, per = timed_conv_pass(yolo, plan)
+    conv_s2, per = timed_conv_pass(yolo, plan)        # second pass: caches / clocks settled
+    conv_s = min(conv_s, conv_s2)
+    achieved = train_fl * BATCH / conv_s / 1e12
+
+    if rank == 0:
+        out = {
+            'metric': 'images/sec (train fwd+bwd) bs=8 416x416',
+            'value': global_batch * args.steps / dt,
+            'unit': 'images/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'train.py step (model.py:481-508): fwd + loss + bwd + Keras Adam%s, batch 8 per GPU, 416x416x3, '
+                                   'anchors [(64,384),(384,64)], 2 classes, fp32 MFMA convs' % (' + RCCL grad all-reduce' if world > 1 else ''),
+                       'global_batch': global_batch, 'per_gpu_batch': BATCH, 'image': [IMG, IMG, 3],
+                       'launch': 'hip-graph' if use_graph else 'eager', 'parallelism': 'dp%d' % world},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'kernel': 'conv_igemm_kernel + conv_wgrad_kernel (MFMA implicit-GEMM conv fwd/dgrad/wgrad), %d launches/step' % sum(v[1] for v in per.values()),
+                         'flops_per_step': train_fl * BATCH, 'kernel_ms_per_step': conv_s * 1e3,
+                         'by_entry_ms': {k: round(v[0] * 1e3, 3) for k, v in per.items()}},
+            'step_flop_rate_tflops': train_fl * BATCH / (dt / args.steps) / 1e12,
+            'final_loss': loss_val,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(seed=1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -116,7 +116,7 @@ int y3_bn_apply(const y3_tensor* a, const float* scale, const float* shift, cons
 int y3_bn_bwd_reduce(const y3_tensor* dy, const y3_tensor* a, const float* save_mean,
                      const float* save_rstd, float alpha, float* partials, int* nparts,
                      y3_stream_t stream);
-int y3_bn_bwd_partials(int m, int c); /* number of partial rows the reduce writes */
+int y3_bn_bwd_partials(int m, int c); /* number of partial rows; `partials` holds rows*5*c DOUBLES (8-byte aligned) */
 int y3_bn_bwd_finalize(const float* partials, int nparts, int c, int count, const float* gamma,
                        const float* save_mean, const float* save_rstd, float alpha,
                        float* dgamma, float* dbeta, float* dbias, float* coef, y3_stream_t stream);

@@ -151,11 +151,13 @@ extern "C" int y3_bn_bwd_partials(int m, int c) {
     return parts;
 }
 
-// partials[part][5][C]: sum dy, sum dy*xhat, sum dy*s, sum s, sum xhat*s   (s = lrelu slope at a)
+// partials[part][5][C] (fp64): sum dy, sum dy*xhat, sum dy*s, sum s, sum xhat*s   (s = lrelu slope at a)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int dy_ld, const float* __restrict__ a, int a_ld,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd, float alpha,
                                                             float* __restrict__ partials, long long npix, int C) {
-    __shared__ float sm[256 * 20];
+    // fp64 accumulation: dbias is a small difference of these sums (BatchNorm removes the mean shift a
+    // bias introduces), so fp32 running sums would lose it to cancellation
+    __shared__ double sm[256 * 20];
     const int c4n = C >> 2;
     const int rpp = 256 / c4n;
     const int cq = threadIdx.x % c4n, rg = threadIdx.x / c4n;
@@ -163,11 +165,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const float4 mu = *reinterpret_cast<const float4*>(mean + c);
     const float4 rs = *reinterpret_cast<const float4*>(rstd + c);
     const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
-    float acc[5][4];
+    double acc[5][4];
 #pragma unroll
     for (int j = 0; j < 5; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[j][e] = 0.f;
+        for (int e = 0; e < 4; ++e) acc[j][e] = 0.0;
     const long long rows_per_block = (npix + gridDim.x - 1) / gridDim.x;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
@@ -178,11 +180,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float xh = (av[e] - muv[e]) * rsv[e];
-            const float s = av[e] > 0.f ? 1.f : alpha;
-            acc[0][e] += dv[e];
-            acc[1][e] += dv[e] * xh;
-            acc[2][e] += dv[e] * s;
+            const double xh = ((double)av[e] - (double)muv[e]) * (double)rsv[e];
+            const double s = av[e] > 0.f ? 1.0 : (double)alpha;
+            const double d = (double)dv[e];
+            acc[0][e] += d;
+            acc[1][e] += d * xh;
+            acc[2][e] += d * s;
             acc[3][e] += s;
             acc[4][e] += xh * s;
         }
@@ -199,8 +202,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[j][e] += sm[(g * c4n + cq) * 20 + j * 4 + e];
 #pragma unroll
-        for (int j = 0; j < 5; ++j)
-            *reinterpret_cast<float4*>(partials + ((long long)blockIdx.x * 5 + j) * C + c) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+        for (int j = 0; j < 5; ++j) {
+            double* dst = reinterpret_cast<double*>(partials) + ((long long)blockIdx.x * 5 + j) * C + c;
+            dst[0] = acc[j][0];
+            dst[1] = acc[j][1];
+            dst[2] = acc[j][2];
+            dst[3] = acc[j][3];
+        }
     }
 }
 
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     if (c < C)
         for (int t = g; t < nparts; t += 32)
 #pragma unroll
-            for (int j = 0; j < 5; ++j) s[j] += (double)partials[((long long)t * 5 + j) * C + c];
+            for (int j = 0; j < 5; ++j) s[j] += reinterpret_cast<const double*>(partials)[((long long)t * 5 + j) * C + c];
 #pragma unroll
     for (int j = 0; j < 5; ++j) sm[j][g][cl] = s[j];
     __syncthreads();

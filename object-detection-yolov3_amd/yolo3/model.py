@@ -212,7 +212,7 @@ class _Plan:
         self.stats_ws = torch.empty(max_mc // 32 + 4096, dtype=torch.float32, device=dev)
         if tr:
             self.dz = torch.empty(max_mc, dtype=torch.float32, device=dev)
-            self.bnb_ws = torch.empty(512 * 5 * 1024, dtype=torch.float32, device=dev)
+            self.bnb_ws = torch.empty(512 * 5 * 1024, dtype=torch.float64, device=dev)
             self.wg_ws_bytes = 0
 
         def ptr(off):

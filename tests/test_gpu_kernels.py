@@ -220,7 +220,7 @@ def test_batchnorm_train_fwd_bwd(hip, shape):
     dyv.copy_(dy)
     DY = hip.Tensor(dyv.data_ptr(), n, h, w, c, c + 4)
     parts = hip.lib.y3_bn_bwd_partials(M, c)
-    pws = torch.empty(parts * 5 * c, device='cuda')
+    pws = torch.empty(parts * 5 * c, device='cuda', dtype=torch.float64)
     npart = C.c_int(0)
     hip.check(hip.lib.y3_bn_bwd_reduce(DY, A, smean.data_ptr(), srstd.data_ptr(), 0.2, pws.data_ptr(), C.byref(npart), stream()))
     assert npart.value == parts
@@ -398,7 +398,8 @@ def test_adam_matches_oracle(hip):
         hip.check(hip.lib.y3_adam_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), count, lr.data_ptr(), 0.9, 0.999, 1e-7, stream()))
     assert_close(p.cpu(), ref_p, rtol=1e-6, what='adam params')
     assert_close(m.cpu(), st.m[0], rtol=1e-5, what='adam m')
-    assert_close(v.cpu(), st.v[0], rtol=1e-5, what='adam v')
+    # 1 - float32(0.999) differs from 0.001 by 1.3e-5 relative: inherent to fp32 hyper-parameters (TF's kernel does the same)
+    assert_close(v.cpu(), st.v[0], rtol=5e-5, what='adam v')
 
 
 def _golden_nms(golden_dir):

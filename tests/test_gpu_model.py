@@ -38,6 +38,12 @@ def _setup(img, n, seed, randomize_bn):
     from yolo3.model import YoloV3
     from test_gpu_kernels import _labels
     params = om.init_params(3, len(ANCHORS), K, seed=seed, randomize_bn=randomize_bn)
+    if randomize_bn:
+        # randomised BN makes activations grow with depth; keep the head logits O(1) so exp() in the decode / loss
+        # stays inside fp32 range (otherwise fp32 and fp64 evaluations of the SAME graph disagree by overflow)
+        for p in params:
+            if 'gamma' not in p:
+                p['W'] *= 0.02
     yolo = YoloV3(n, [img, img, 3], K, ANCHORS, learning_rate=1e-3)
     yolo.set_weights(params)
     g = torch.Generator().manual_seed(seed)
@@ -73,8 +79,10 @@ def test_inference_matches_oracle(img, n):
     for i in range(3):
         _check(fm_gpu[i], refs[torch.float32][1][i], refs[torch.float64][1][i], 'feature_map_%d' % (i + 1))
     _check(out[..., 4:], refs[torch.float32][0][..., 4:], refs[torch.float64][0][..., 4:], 'scores')
-    # boxes: exp() amplifies logit noise; compare in log-size / centre space through the scores' bound on the logits
-    _check(out[..., :4], refs[torch.float32][0][..., :4], refs[torch.float64][0][..., :4], 'boxes', mult=10.0)
+    # boxes: exp() turns logit noise into relative noise, so compare relative to the box magnitude
+    b32, b64 = refs[torch.float32][0][..., :4], refs[torch.float64][0][..., :4]
+    den = np.abs(b64) + 1.0
+    _check(out[..., :4] / den, b32 / den, b64 / den, 'boxes', mult=10.0)
 
 
 def test_train_step_matches_oracle():
