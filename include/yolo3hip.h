@@ -63,8 +63,11 @@ typedef struct y3_tensor {
 int y3_conv2d_fwd(const y3_tensor* src, const float* wt, const float* bias, int ksize, int stride,
                   const y3_tensor* dst, unsigned flags, float alpha,
                   const float* scale, const float* shift, const y3_tensor* resid,
-                  float* stats, y3_stream_t stream);
-int y3_conv2d_stats_tiles(int m, int cout);
+                  float* stats, void* workspace, size_t workspace_bytes, y3_stream_t stream);
+/* m = output pixels (N*OH*OW).  Layers with few output tiles are split along K; the partial slabs live in
+ * `workspace` (y3_conv2d_fwd_workspace bytes; passing less only disables the split when stats == NULL). */
+int y3_conv2d_stats_tiles(int m, int cin, int ksize, int cout);
+size_t y3_conv2d_fwd_workspace(int m, int cin, int ksize, int cout);
 
 /*
  * Gradient w.r.t. the conv input (tape.gradient, model.py:496):
@@ -74,7 +77,9 @@ int y3_conv2d_stats_tiles(int m, int cout);
  * the forward), dsrc has the forward's src geometry.
  */
 int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksize, int stride,
-                    const y3_tensor* dsrc, unsigned flags, y3_stream_t stream);
+                    const y3_tensor* dsrc, unsigned flags, void* workspace, size_t workspace_bytes,
+                    y3_stream_t stream);
+size_t y3_conv2d_dgrad_workspace(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc);
 
 /*
  * Gradient w.r.t. the kernel:  dw[tap][ci][co] = sum_pixels src*ddst.

@@ -17,6 +17,8 @@
 //   B: ds_read_b32, 32 consecutive n per half-wave (conflict-free)
 // The k order inside a K step is permuted identically for A and B
 // (lane half h takes k = 8*kk + 4*h + i), which only reorders the fp32 sum.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct ConvArgs {
@@ -38,6 +40,7 @@ struct ConvArgs {
     unsigned flags;
     float alpha;
     int nbn;
+    int src_n, wt_rows;  // host-side only: batch of src, rows of the weight matrix (descriptor sizes)
 };
 
 template <int BM, int BN, int WM, int WN, int BK>
@@ -257,6 +260,321 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
 }
 
 // ---------------------------------------------------------------------------
+// Fast path of the same gather-GEMM (taken when C % BK == 0 and Nout % 4 == 0, i.e. every layer except
+// the first conv and the 14-channel heads): a K step never straddles a tap, so the tap and the channel
+// base are wave-uniform and travel in the scalar offset of buffer loads; per-lane offsets are loop
+// invariant; padding / tile-edge lanes are pointed past the descriptor's range and read zeros from the
+// hardware bounds check instead of branching.
+// ---------------------------------------------------------------------------
+struct FastArgs {
+    const float* src;  // biased so that every tap offset is >= 0
+    const float* wt;
+    float* dst;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    const float* resid;
+    float* stats;
+    int tap_off[9];   // byte offset of tap t from the pixel base (biased, >= 0)
+    int tap_wrow[9];  // weight row of tap t, channel 0
+    int tap_dh[9], tap_dw[9];
+    unsigned src_bytes, wt_bytes;
+    int ntaps;
+    int H, W, logC, cmask, src_ld;
+    int OH, OW, sh, sw;
+    int DH, DW, dsh, dsw, doh, dow, dst_ld;
+    int resid_ld;
+    int Nout, K, M;
+    unsigned flags;
+    float alpha;
+    int nbn;
+    int ksplit, kchunk;  // split-K: grid = tiles * ksplit, slice z covers K range [z*kchunk, (z+1)*kchunk)
+    float* slab;         // [ksplit][M][Nout] raw partial sums when ksplit > 1
+};
+
+#define Y3_OOB 0x80000000u
+
+template <int BM, int BN, int WM, int WN, int BK, bool DENSE>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_fast_kernel(const FastArgs p) {
+    constexpr int THREADS = 64 * WM * WN;
+    constexpr int LDA = BK + 4;
+    constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
+    constexpr int KV = BK / 4;
+    constexpr int A_TOTAL = BM * KV, A_LOADS = A_TOTAL / THREADS;
+    constexpr int BN4 = BN / 4;
+    constexpr int B_TOTAL = BK * BN4, B_LOADS = (B_TOTAL + THREADS - 1) / THREADS;
+    static_assert(A_TOTAL % THREADS == 0 && THREADS % KV == 0 && TM % 32 == 0 && TN % 32 == 0, "tile shape");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+    __shared__ float red[2][WM][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int bid0 = y3_xcd_remap(blockIdx.x, gridDim.x);
+    const int kz = bid0 % p.ksplit;
+    const int bid = bid0 / p.ksplit;
+    const int bm = bid / p.nbn, bn = bid % p.nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int ohw = p.OH * p.OW;
+    const int kbeg = kz * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.wt_bytes, 0x00020000);
+
+    // loop-invariant per-lane offsets
+    unsigned a_voff[A_LOADS], a_mask[A_LOADS];
+    const int a_kv = tid % KV;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int row = (tid + i * THREADS) / KV;
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / ohw;
+        const int r = mm - n * ohw;
+        const int oh = r / p.OW;
+        const int ow = r - oh * p.OW;
+        const int ih0 = oh * p.sh, iw0 = ow * p.sw;
+        a_voff[i] = (unsigned)(((n * p.H + ih0) * p.W + iw0) * p.src_ld + a_kv * 4) * 4u;
+        unsigned msk = 0;
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int ih = ih0 + p.tap_dh[t], iw = iw0 + p.tap_dw[t];
+            if (ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) msk |= 1u << t;
+        }
+        a_mask[i] = msk;
+    }
+    unsigned b_voff[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int idx = tid + i * THREADS;
+        const int kr = idx / BN4, n = n0 + (idx % BN4) * 4;
+        b_voff[i] = (idx < B_TOTAL && n < p.Nout) ? (unsigned)(kr * p.Nout + n) * 4u : Y3_OOB;
+    }
+
+    f32x4 ra[A_LOADS], rb[B_LOADS];
+    auto gload = [&](int k0) {
+        const int tap = k0 >> p.logC;  // wave-uniform: scalar unit
+        const int cb = k0 & p.cmask;
+        const unsigned a_soff = (unsigned)(p.tap_off[tap] + cb * 4);
+        const unsigned b_soff = (unsigned)((p.tap_wrow[tap] + cb) * p.Nout) * 4u;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const unsigned vo = ((a_mask[i] >> tap) & 1u) ? a_voff[i] : Y3_OOB;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, vo, a_soff, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[i], b_soff, 0);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) *reinterpret_cast<f32x4*>(&As[buf][((tid + i * THREADS) / KV) * LDA + a_kv * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int idx = tid + i * THREADS;
+            if (B_TOTAL % THREADS == 0 || idx < B_TOTAL) *reinterpret_cast<f32x4*>(&Bs[buf][(idx / BN4) * BN + (idx % BN4) * 4]) = rb[i];
+        }
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (kend - kbeg) / BK;
+    gload(kbeg);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        const bool more = ks + 1 < nk;
+        if (more) gload(kbeg + (ks + 1) * BK);
+        const float* as = &As[cur][(wm * TM + l31) * LDA + lh * 4];
+        const float* bs = &Bs[cur][(lh * 4) * BN + wn * TN + l31];
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 av[MB];
+            float bv[NB][4];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) av[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDA + kk * 8);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[j][q] = bs[(kk * 8 + q) * BN + j * 32];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (p.slab) {
+        // split-K: raw partial sums; bias / activation / statistics are applied by splitk_epilogue_kernel
+        float* out = p.slab + (long long)kz * p.M * p.Nout;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int n = n0 + wn * TN + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < p.M && n < p.Nout) out[(long long)m * p.Nout + n] = acc[i][j][r];
+                }
+        }
+        return;
+    }
+
+    // ---- epilogue (same contract as conv_igemm_kernel)
+    const bool do_lrelu = p.flags & Y3_EPI_LRELU;
+    const bool do_accum = p.flags & Y3_EPI_ACCUM;
+    float ssum[NB], ssq[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) ssum[j] = ssq[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * TN + j * 32 + l31;
+        const bool nok = n < p.Nout;
+        const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+        const float sc = (p.scale && nok) ? p.scale[n] : 1.f;
+        const float sf = (p.scale && nok) ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < p.M && nok) {
+                    float v = acc[i][j][r] + bias;
+                    if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
+                    ssum[j] += v;
+                    ssq[j] += v * v;
+                    long long pix;
+                    if (DENSE) {
+                        pix = m;
+                    } else {
+                        const int nimg = m / ohw;
+                        const int rr = m - nimg * ohw;
+                        const int oh = rr / p.OW;
+                        const int ow = rr - oh * p.OW;
+                        pix = ((long long)nimg * p.DH + oh * p.dsh + p.doh) * p.DW + ow * p.dsw + p.dow;
+                    }
+                    if (p.scale) v = v * sc + sf;
+                    if (p.resid) v += p.resid[pix * p.resid_ld + n];
+                    float* d = p.dst + pix * p.dst_ld + n;
+                    if (do_accum) v += *d;
+                    *d = v;
+                }
+            }
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float s = ssum[j] + __shfl_xor(ssum[j], 32);
+            const float q = ssq[j] + __shfl_xor(ssq[j], 32);
+            if (lh == 0) {
+                red[0][wm][wn * TN + j * 32 + l31] = s;
+                red[1][wm][wn * TN + j * 32 + l31] = q;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < 2 * BN; c += THREADS) {
+            const int which = c / BN, col = c % BN;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) s += red[which][w][col];
+            const int n = n0 + col;
+            if (n < p.Nout) p.stats[((long long)bm * 2 + which) * p.Nout + n] = s;
+        }
+    }
+}
+
+// Split-K combine + the conv epilogue: v = sum_z slab[z][m][n] + bias -> lrelu -> stats -> affine -> + resid -> (+)= dst.
+// One block = 32 rows x Nout columns (float4 per thread along n); per-block partial statistics like the conv kernel's.
+#define Y3_SK_ROWS 32
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const FastArgs p) {
+    __shared__ float red[2][256 * 4];
+    const int c4n = p.Nout >> 2;
+    const int cw = c4n < 256 ? c4n : 256;
+    const int lanes = 256 / cw;
+    const int cq = threadIdx.x % cw, rl = threadIdx.x / cw;
+    const int r0 = blockIdx.x * Y3_SK_ROWS;
+    const int ohw = p.OH * p.OW;
+    const bool do_lrelu = p.flags & Y3_EPI_LRELU;
+    const bool do_accum = p.flags & Y3_EPI_ACCUM;
+    const bool dense = p.dsh == 1 && p.dsw == 1 && p.doh == 0 && p.dow == 0 && p.DH == p.OH && p.DW == p.OW;
+    const long long slab_stride = (long long)p.M * p.Nout;
+    for (int c4 = cq; c4 < c4n; c4 += cw) {
+        const int n = c4 * 4;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.scale) {
+            sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+            sf = *reinterpret_cast<const f32x4*>(p.shift + n);
+        }
+        f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+        if (rl < lanes)
+            for (int r = rl; r < Y3_SK_ROWS; r += lanes) {
+                const int m = r0 + r;
+                if (m >= p.M) break;
+                const float* s = p.slab + (long long)m * p.Nout + n;
+                f32x4 v = *reinterpret_cast<const f32x4*>(s);
+                for (int z = 1; z < p.ksplit; ++z) v += *reinterpret_cast<const f32x4*>(s + z * slab_stride);
+                v += bias;
+                if (do_lrelu)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : p.alpha * v[e];
+                ssum += v;
+                ssq += v * v;
+                long long pix;
+                if (dense) {
+                    pix = m;
+                } else {
+                    const int nimg = m / ohw;
+                    const int rr = m - nimg * ohw;
+                    const int oh = rr / p.OW;
+                    const int ow = rr - oh * p.OW;
+                    pix = ((long long)nimg * p.DH + oh * p.dsh + p.doh) * p.DW + ow * p.dsw + p.dow;
+                }
+                if (p.scale) v = v * sc + sf;
+                if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + pix * p.resid_ld + n);
+                float* d = p.dst + pix * p.dst_ld + n;
+                if (do_accum) v += *reinterpret_cast<const f32x4*>(d);
+                *reinterpret_cast<f32x4*>(d) = v;
+            }
+        if (p.stats) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[0][threadIdx.x * 4 + e] = ssum[e];
+                red[1][threadIdx.x * 4 + e] = ssq[e];
+            }
+            __syncthreads();
+            if (rl == 0) {
+                for (int g = 1; g < lanes; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ssum[e] += red[0][(g * cw + cq) * 4 + e];
+                        ssq[e] += red[1][(g * cw + cq) * 4 + e];
+                    }
+                *reinterpret_cast<f32x4*>(p.stats + ((long long)blockIdx.x * 2 + 0) * p.Nout + n) = ssum;
+                *reinterpret_cast<f32x4*>(p.stats + ((long long)blockIdx.x * 2 + 1) * p.Nout + n) = ssq;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // kernel gradient: out[z][k][n] = sum_{m in chunk z} A[m][k] * ddst[m][n]
 // ---------------------------------------------------------------------------
 struct WgradArgs {
@@ -462,36 +780,223 @@ static int check_tensor(const y3_tensor* t, const char* name) {
 }
 
 struct TileCfg {
-    int bm, bn;
+    int bm, bn, bk;
 };
 
-// pick the tile that keeps the most SIMDs busy for this (M, Nout)
+// Tuning override (development only): Y3_TILE="bm,bn,bk" forces one configuration for every launch.
+static bool tile_override(TileCfg* t) {
+    static int state = 0;  // 0 unknown, 1 none, 2 set
+    static TileCfg forced;
+    if (state == 0) {
+        const char* e = getenv("Y3_TILE");
+        state = 1;
+        if (e && sscanf(e, "%d,%d,%d", &forced.bm, &forced.bn, &forced.bk) == 3) state = 2;
+    }
+    if (state == 2) *t = forced;
+    return state == 2;
+}
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// Tile choice from the measured sweep (tools/conv_tune.py, MI355X): a launch wants >= ~600 workgroups
+// (256 CUs x 2-3 resident); prefer the largest tile that still gives that many, else 64x64 (+ split-K).
 static TileCfg pick_tile(int M, int Nout) {
-    if (Nout <= 32) return {128, 32};
-    if (Nout <= 64) return {128, 64};
-    const long long big = (long long)y3_cdiv(M, 128) * y3_cdiv(Nout, 128);
-    if (big >= 256) return {128, 128};
-    return {64, 64};
+    TileCfg t;
+    if (Nout <= 32)
+        t = {128, 32, 16};
+    else if (Nout <= 64)
+        t = {128, 64, 16};
+    else {
+        const long long t128 = (long long)y3_cdiv(M, 128) * y3_cdiv(Nout, 128);
+        const long long t64x128 = (long long)y3_cdiv(M, 64) * y3_cdiv(Nout, 128);
+        if (t128 >= 600)
+            t = {128, 128, 16};
+        else if (t64x128 >= 600)
+            t = {64, 128, 16};
+        else
+            t = {64, 64, 16};
+    }
+    TileCfg f;
+    if (tile_override(&f) && f.bn <= ((Nout + 31) / 32) * 32) t = f;
+    return t;
 }
 
-int y3_conv2d_stats_tiles(int m, int cout) {
-    TileCfg t = pick_tile(m, cout);
-    return y3_cdiv(m, t.bm);
+struct ConvPlan {
+    TileCfg t;
+    int ksplit, kchunk, stats_tiles;
+    size_t ws_bytes;
+};
+// fast_ok: the launch qualifies for conv_igemm_fast_kernel (the only kernel with split-K)
+static ConvPlan plan_conv(int M, int Nout, int K, bool fast_ok) {
+    ConvPlan pl;
+    pl.t = pick_tile(M, Nout);
+    pl.ksplit = 1;
+    pl.kchunk = K;
+    const long long tiles = (long long)y3_cdiv(M, pl.t.bm) * y3_cdiv(Nout, pl.t.bn);
+    static const int want = env_int("Y3_SPLITK_WGS", 1400);   // workgroups to aim for
+    static const int min_k = env_int("Y3_SPLITK_MINK", 256);  // shortest K slice worth a launch
+    if (fast_ok && Nout <= 1024 && tiles * 2 <= want && K >= 2 * min_k) {
+        int ks = (int)((want + tiles / 2) / tiles);
+        const int maxs = K / min_k;
+        if (ks > maxs) ks = maxs;
+        if (ks > 16) ks = 16;
+        if (ks > 1) {
+            int chunk = y3_cdiv(K, ks);
+            chunk = y3_cdiv(chunk, pl.t.bk) * pl.t.bk;
+            pl.ksplit = y3_cdiv(K, chunk);
+            pl.kchunk = chunk;
+        }
+    }
+    pl.stats_tiles = pl.ksplit > 1 ? y3_cdiv(M, Y3_SK_ROWS) : y3_cdiv(M, pl.t.bm);
+    pl.ws_bytes = pl.ksplit > 1 ? (size_t)pl.ksplit * M * Nout * sizeof(float) : 0;
+    return pl;
+}
+static bool fast_shape_ok(int C, int Nout, int K, int ntaps) {
+    return !getenv("Y3_NO_FAST") && C % 16 == 0 && (Nout & 3) == 0 && K % 16 == 0 && (ntaps == 1 || y3_is_pow2(C));
 }
 
-static int launch_igemm(const ConvArgs& a, hipStream_t st) {
-    ConvArgs p = a;
-    const TileCfg t = pick_tile(p.M, p.Nout);
-    p.nbn = y3_cdiv(p.Nout, t.bn);
-    const int grid = y3_cdiv(p.M, t.bm) * p.nbn;
-    if (t.bm == 128 && t.bn == 128)
-        hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, 16>), dim3(grid), dim3(256), 0, st, p);
-    else if (t.bm == 128 && t.bn == 64)
-        hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 4, 1, 16>), dim3(grid), dim3(256), 0, st, p);
-    else if (t.bm == 128 && t.bn == 32)
-        hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, 16>), dim3(grid), dim3(256), 0, st, p);
+extern "C" int y3_conv2d_stats_tiles(int m, int cin, int ksize, int cout) {
+    const int taps = ksize * ksize;
+    return plan_conv(m, cout, taps * cin, fast_shape_ok(cin, cout, taps * cin, taps)).stats_tiles;
+}
+extern "C" size_t y3_conv2d_fwd_workspace(int m, int cin, int ksize, int cout) {
+    const int taps = ksize * ksize;
+    return plan_conv(m, cout, taps * cin, fast_shape_ok(cin, cout, taps * cin, taps)).ws_bytes;
+}
+
+template <int BM, int BN, int WM, int WN, int BK>
+static void launch_cfg(const ConvArgs& p, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
+}
+template <int BM, int BN, int WM, int WN, int BK>
+static void launch_fast(const FastArgs& p, bool dense, int grid, hipStream_t st) {
+    if (dense)
+        hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, true>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 2, 2, 16>), dim3(grid), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, false>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
+}
+
+// Build the fast kernel's arguments; false if the launch does not qualify.
+static bool make_fast(const ConvArgs& a, int ntaps, int bk, FastArgs* f) {
+    if (a.C % bk != 0 || (a.Nout & 3) != 0 || a.K % bk != 0) return false;
+    if (ntaps > 1 && !y3_is_pow2(a.C)) return false;
+    const long long src_elems = (long long)(a.M > 0 ? 1 : 0) * 0;  // (unused)
+    (void)src_elems;
+    FastArgs p = {};
+    // bias the base pointer by the most negative tap offset so that scalar offsets stay non-negative
+    int min_off = 0;
+    int dh[9], dw[9];
+    for (int t = 0; t < ntaps; ++t) {
+        const int code = (int)((a.tap_dhdw >> (4 * t)) & 15ull);
+        dh[t] = (code & 3) - 1;
+        dw[t] = (code >> 2) - 1;
+        const int off = (dh[t] * a.W + dw[t]) * a.src_ld;
+        if (off < min_off) min_off = off;
+    }
+    const long long total = (long long)a.src_n * a.H * a.W * a.src_ld - min_off;
+    const long long wtotal = (long long)(a.wt_rows) * a.Nout;
+    if (total * 4 >= 0x7fffffffLL || wtotal * 4 >= 0x7fffffffLL) return false;
+    p.src = a.src + min_off;
+    p.src_bytes = (unsigned)(total * 4);
+    p.wt = a.wt;
+    p.wt_bytes = (unsigned)(wtotal * 4);
+    for (int t = 0; t < ntaps; ++t) {
+        p.tap_dh[t] = dh[t];
+        p.tap_dw[t] = dw[t];
+        p.tap_off[t] = ((dh[t] * a.W + dw[t]) * a.src_ld - min_off) * 4;
+        p.tap_wrow[t] = (int)((a.tap_wsel >> (4 * t)) & 15ull) * a.C;
+    }
+    p.ntaps = ntaps;
+    p.dst = a.dst;
+    p.bias = a.bias;
+    p.scale = a.scale;
+    p.shift = a.shift;
+    p.resid = a.resid;
+    p.stats = a.stats;
+    p.H = a.H;
+    p.W = a.W;
+    p.logC = a.logC;
+    p.cmask = a.cmask;
+    p.src_ld = a.src_ld;
+    p.OH = a.OH;
+    p.OW = a.OW;
+    p.sh = a.sh;
+    p.sw = a.sw;
+    p.DH = a.DH;
+    p.DW = a.DW;
+    p.dsh = a.dsh;
+    p.dsw = a.dsw;
+    p.doh = a.doh;
+    p.dow = a.dow;
+    p.dst_ld = a.dst_ld;
+    p.resid_ld = a.resid_ld;
+    p.Nout = a.Nout;
+    p.K = a.K;
+    p.M = a.M;
+    p.flags = a.flags;
+    p.alpha = a.alpha;
+    *f = p;
+    return true;
+}
+
+static int launch_igemm(const ConvArgs& a, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    ConvArgs p = a;
+    const int ntaps = p.K / p.C;
+    const bool fast_ok = fast_shape_ok(p.C, p.Nout, p.K, ntaps);
+    ConvPlan pl = plan_conv(p.M, p.Nout, p.K, fast_ok);
+    if (pl.ksplit > 1 && (workspace == nullptr || workspace_bytes < pl.ws_bytes)) {  // no room for slabs: single pass
+        pl.ksplit = 1;
+        pl.kchunk = p.K;
+        if (p.stats) {
+            y3_set_error("conv: workspace %zu < %zu needed by the planned split-K launch", workspace_bytes, pl.ws_bytes);
+            return Y3_EINVAL;  // the caller sized `stats` for the split-K plan
+        }
+    }
+    const TileCfg t = pl.t;
+    p.nbn = y3_cdiv(p.Nout, t.bn);
+    const int tiles = y3_cdiv(p.M, t.bm) * p.nbn;
+    const int key = t.bm * 10000 + t.bn * 10 + (t.bk == 32 ? 1 : 0);
+    FastArgs f;
+    if (fast_ok && make_fast(p, ntaps, t.bk, &f)) {
+        f.nbn = p.nbn;
+        f.ksplit = pl.ksplit;
+        f.kchunk = pl.kchunk;
+        f.slab = pl.ksplit > 1 ? (float*)workspace : nullptr;
+        const int grid = tiles * pl.ksplit;
+        const bool dense = p.dense_dst != 0;
+        switch (key) {
+            case 128 * 10000 + 128 * 10 + 0: launch_fast<128, 128, 2, 2, 16>(f, dense, grid, st); break;
+            case 128 * 10000 + 128 * 10 + 1: launch_fast<128, 128, 2, 2, 32>(f, dense, grid, st); break;
+            case 128 * 10000 + 64 * 10 + 0: launch_fast<128, 64, 4, 1, 16>(f, dense, grid, st); break;
+            case 128 * 10000 + 64 * 10 + 1: launch_fast<128, 64, 4, 1, 32>(f, dense, grid, st); break;
+            case 128 * 10000 + 32 * 10 + 0: launch_fast<128, 32, 4, 1, 16>(f, dense, grid, st); break;
+            case 128 * 10000 + 32 * 10 + 1: launch_fast<128, 32, 4, 1, 32>(f, dense, grid, st); break;
+            case 64 * 10000 + 64 * 10 + 0: launch_fast<64, 64, 2, 2, 16>(f, dense, grid, st); break;
+            case 64 * 10000 + 64 * 10 + 1: launch_fast<64, 64, 2, 2, 32>(f, dense, grid, st); break;
+            case 64 * 10000 + 128 * 10 + 0: launch_fast<64, 128, 2, 2, 16>(f, dense, grid, st); break;
+            case 64 * 10000 + 128 * 10 + 1: launch_fast<64, 128, 2, 2, 32>(f, dense, grid, st); break;
+            case 256 * 10000 + 128 * 10 + 0: launch_fast<256, 128, 4, 2, 16>(f, dense, grid, st); break;
+            case 256 * 10000 + 128 * 10 + 1: launch_fast<256, 128, 4, 2, 32>(f, dense, grid, st); break;
+            default: y3_set_error("conv: no fast kernel for tile %dx%dx%d", t.bm, t.bn, t.bk); return Y3_EINVAL;
+        }
+        Y3_CHECK_LAUNCH("conv_igemm_fast");
+        if (pl.ksplit > 1) {
+            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(y3_cdiv(p.M, Y3_SK_ROWS)), dim3(256), 0, st, f);
+            Y3_CHECK_LAUNCH("splitk_epilogue");
+        }
+        return Y3_OK;
+    }
+    const int grid = tiles;
+    switch (key) {
+        case 128 * 10000 + 128 * 10 + 0: launch_cfg<128, 128, 2, 2, 16>(p, grid, st); break;
+        case 128 * 10000 + 64 * 10 + 0: launch_cfg<128, 64, 4, 1, 16>(p, grid, st); break;
+        case 128 * 10000 + 32 * 10 + 0: launch_cfg<128, 32, 4, 1, 16>(p, grid, st); break;
+        case 64 * 10000 + 64 * 10 + 0: launch_cfg<64, 64, 2, 2, 16>(p, grid, st); break;
+        case 64 * 10000 + 128 * 10 + 0: launch_cfg<64, 128, 2, 2, 16>(p, grid, st); break;
+        default: y3_set_error("conv: no generic kernel for tile %dx%dx%d", t.bm, t.bn, t.bk); return Y3_EINVAL;
+    }
     Y3_CHECK_LAUNCH("conv_igemm");
     return Y3_OK;
 }
@@ -510,7 +1015,7 @@ static int set_channels(int C, int taps, int* logC, int* cmask) {
 
 extern "C" int y3_conv2d_fwd(const y3_tensor* src, const float* wt, const float* bias, int ksize, int stride, const y3_tensor* dst,
                              unsigned flags, float alpha, const float* scale, const float* shift, const y3_tensor* resid, float* stats,
-                             y3_stream_t stream) {
+                             void* workspace, size_t workspace_bytes, y3_stream_t stream) {
     if (int e = check_tensor(src, "conv2d_fwd src")) return e;
     if (int e = check_tensor(dst, "conv2d_fwd dst")) return e;
     Y3_CHECK_ARG(wt, "conv2d_fwd: null weights");
@@ -563,11 +1068,29 @@ extern "C" int y3_conv2d_fwd(const y3_tensor* src, const float* wt, const float*
     p.M = src->n * OH * OW;
     p.flags = flags;
     p.alpha = alpha;
-    return launch_igemm(p, (hipStream_t)stream);
+    p.src_n = src->n;
+    p.wt_rows = taps * src->c;
+    return launch_igemm(p, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t y3_conv2d_dgrad_workspace(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc) {
+    const int taps = ksize * ksize;
+    if (stride == 1) {
+        const int K = taps * ddst->c;
+        return plan_conv(dsrc->n * dsrc->h * dsrc->w, dsrc->c, K, fast_shape_ok(ddst->c, dsrc->c, K, taps)).ws_bytes;
+    }
+    size_t best = 0;
+    for (int nt = 1; nt <= 4; nt *= 2) {  // parity classes carry 1, 2, 2 and 4 taps of a 3x3 kernel
+        const int K = nt * ddst->c;
+        const int M = dsrc->n * ((dsrc->h + 1) / 2) * ((dsrc->w + 1) / 2);
+        const size_t b = plan_conv(M, dsrc->c, K, fast_shape_ok(ddst->c, dsrc->c, K, nt)).ws_bytes;
+        if (b > best) best = b;
+    }
+    return best;
 }
 
 extern "C" int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc, unsigned flags,
-                               y3_stream_t stream) {
+                               void* workspace, size_t workspace_bytes, y3_stream_t stream) {
     if (int e = check_tensor(ddst, "conv2d_dgrad ddst")) return e;
     if (int e = check_tensor(dsrc, "conv2d_dgrad dsrc")) return e;
     Y3_CHECK_ARG(wt_t, "conv2d_dgrad: null weights");
@@ -592,6 +1115,8 @@ extern "C" int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksi
     base.DH = dsrc->h;
     base.DW = dsrc->w;
     base.sh = base.sw = 1;
+    base.src_n = ddst->n;
+    base.wt_rows = ksize * ksize * ddst->c;
     if (stride == 1) {
         ConvArgs p = base;
         const int taps = ksize * ksize;
@@ -609,7 +1134,7 @@ extern "C" int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksi
         p.dense_dst = 1;
         p.K = taps * ddst->c;
         p.M = dsrc->n * p.OH * p.OW;
-        return launch_igemm(p, (hipStream_t)stream);
+        return launch_igemm(p, workspace, workspace_bytes, (hipStream_t)stream);
     }
     // stride 2: forward out o reads in[2o + k - pad]; input pixel i = 2q + par receives from the taps with
     // (par + pad - k) even, at o = q + (par + pad - k)/2.  One launch per (row parity, col parity).
@@ -646,7 +1171,7 @@ extern "C" int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksi
                 p.cmask = 0x7fffffff;
             }
             p.K = nt * ddst->c;
-            if (int e = launch_igemm(p, (hipStream_t)stream)) return e;
+            if (int e = launch_igemm(p, workspace, workspace_bytes, (hipStream_t)stream)) return e;
         }
     return Y3_OK;
 }

@@ -40,9 +40,11 @@ i32, u32, f32, sz = C.c_int, C.c_uint, C.c_float, C.c_size_t
 SIGNATURES = {
     'y3_last_error': (C.c_char_p, []),
     'y3_version': (i32, []),
-    'y3_conv2d_fwd': (i32, [TP, fp, fp, i32, i32, TP, u32, f32, fp, fp, TP, fp, vp]),
-    'y3_conv2d_stats_tiles': (i32, [i32, i32]),
-    'y3_conv2d_dgrad': (i32, [TP, fp, i32, i32, TP, u32, vp]),
+    'y3_conv2d_fwd': (i32, [TP, fp, fp, i32, i32, TP, u32, f32, fp, fp, TP, fp, vp, sz, vp]),
+    'y3_conv2d_stats_tiles': (i32, [i32, i32, i32, i32]),
+    'y3_conv2d_fwd_workspace': (sz, [i32, i32, i32, i32]),
+    'y3_conv2d_dgrad': (i32, [TP, fp, i32, i32, TP, u32, vp, sz, vp]),
+    'y3_conv2d_dgrad_workspace': (sz, [TP, i32, i32, TP]),
     'y3_conv2d_wgrad': (i32, [TP, TP, i32, i32, fp, vp, sz, vp]),
     'y3_conv2d_wgrad_workspace': (sz, [TP, TP, i32, i32]),
     'y3_transpose_weights': (i32, [fp, fp, i32, i32, i32, vp]),

@@ -173,6 +173,7 @@ class _Plan:
         self.fwd = []      # [(cfunc, args)]   stream appended at run time
         self.bwd = []
         self.keep = []     # ctypes objects / tensors that must outlive the lists
+        self.tensors = []
         self.graph = None
         self._build()
 
@@ -181,11 +182,31 @@ class _Plan:
         ld = c if ld is None else ld
         numel = n * h * w * ld
         buf = (torch.zeros if zero else torch.empty)(numel, dtype=torch.float32, device=self.model.device)
-        return _T(buf, n, h, w, c, ld)
+        t = _T(buf, n, h, w, c, ld)
+        self.tensors.append(t)      # the launch lists hold raw pointers only: keep every buffer alive with the plan
+        return t
 
     def _emit(self, lst, fn, *args):
         self.keep.append(args)
         lst.append((fn, args))
+
+    def _conv_call(self, lst, m, sp, fn, *args, need=None):
+        """Emit a conv launch that may use the shared split-K workspace (allocated after the walk)."""
+        if need is None:
+            need = int(lib.y3_conv2d_fwd_workspace(m, sp.cin_pad, sp.k, sp.cout))
+        self.conv_ws_bytes = max(self.conv_ws_bytes, need)
+        entry = [fn, args]
+        self._conv_ws_users.append(entry)
+        lst.append(entry)
+
+    def _bind_conv_workspace(self):
+        self.conv_ws = torch.empty(max(self.conv_ws_bytes // 4, 4), dtype=torch.float32, device=self.model.device)
+        for lst in (self.fwd, self.bwd):
+            for i, e in enumerate(lst):
+                if isinstance(e, list):
+                    fn, args = e
+                    lst[i] = (fn, tuple(args) + (self.conv_ws.data_ptr(), self.conv_ws_bytes))
+        self.keep.append(self._conv_ws_users)
 
     # -- network walk (model.py:356-421) ---------------------------------------
     def _build(self):
@@ -201,6 +222,7 @@ class _Plan:
         tr = self.training
         self.in_nchw = torch.zeros(N, C, H, W, dtype=torch.float32, device=dev)
         self.ops = []      # high-level records for the backward emission
+        self.layer_out = []  # output activation of every conv_layer, creation order (debug / tests)
         li = [0]
 
         x0 = self._new(N, H, W, specs[0].cin_pad, zero=True)
@@ -209,7 +231,11 @@ class _Plan:
         # shared workspaces.  The largest M*Cout of the net is conv1's (full resolution, FILTER_COUNT/32
         # channels); BN partial statistics need <= 2*Cout floats per row tile of >= 64 rows.
         max_mc = N * H * W * max(YoloV3.FILTER_COUNT // 32, Dld)
-        self.stats_ws = torch.empty(max_mc // 32 + 4096, dtype=torch.float32, device=dev)
+        self.stats_ws = torch.empty(max_mc // 16 + 8192, dtype=torch.float32, device=dev)
+        # split-K slabs of the small-spatial layers (y3_conv2d_fwd_workspace / _dgrad_workspace); 64 MiB covers every layer
+        # of the 416 / 608 configurations, the exact need is checked per layer below
+        self.conv_ws_bytes = 0
+        self._conv_ws_users = []
         if tr:
             self.dz = torch.empty(max_mc, dtype=torch.float32, device=dev)
             self.bnb_ws = torch.empty(512 * 5 * 1024, dtype=torch.float64, device=dev)
@@ -232,17 +258,19 @@ class _Plan:
             mvar = mdl.moving.data_ptr() + 4 * (mdl.moving_stride + sp.mv_off)
             if tr:
                 a = self._new(N, oh, ow, sp.cout)
-                tiles = lib.y3_conv2d_stats_tiles(a.m, sp.cout)
-                self._emit(self.fwd, lib.y3_conv2d_fwd, src.v, ptr(sp.w_off), ptr(sp.b_off), sp.k, sp.s, a.v, EPI_LRELU, LRELU_ALPHA,
-                           None, None, None, self.stats_ws.data_ptr())
+                tiles = lib.y3_conv2d_stats_tiles(a.m, sp.cin_pad, sp.k, sp.cout)
+                assert tiles * 2 * sp.cout <= self.stats_ws.numel()
+                self._conv_call(self.fwd, a.m, sp, lib.y3_conv2d_fwd, src.v, ptr(sp.w_off), ptr(sp.b_off), sp.k, sp.s, a.v, EPI_LRELU,
+                                LRELU_ALPHA, None, None, None, self.stats_ws.data_ptr())
                 self._emit(self.fwd, lib.y3_bn_stats_finalize, self.stats_ws.data_ptr(), tiles, sp.cout, a.m, ptr(sp.g_off), ptr(sp.be_off),
                            BN_EPS, BN_MOMENTUM, mmean, mvar, smean, srstd, scale, shift)
                 self._emit(self.fwd, lib.y3_bn_apply, a.v, scale, shift, resid.v if resid is not None else None, y.v)
                 self.ops.append(('conv_layer', i, src, a, y, resid, (smean, srstd, coef)))
             else:
                 self._emit(self.fwd, lib.y3_bn_fold_inference, ptr(sp.g_off), ptr(sp.be_off), mmean, mvar, BN_EPS, sp.cout, scale, shift)
-                self._emit(self.fwd, lib.y3_conv2d_fwd, src.v, ptr(sp.w_off), ptr(sp.b_off), sp.k, sp.s, y.v, EPI_LRELU, LRELU_ALPHA,
-                           scale, shift, resid.v if resid is not None else None, None)
+                self._conv_call(self.fwd, y.m, sp, lib.y3_conv2d_fwd, src.v, ptr(sp.w_off), ptr(sp.b_off), sp.k, sp.s, y.v, EPI_LRELU,
+                                LRELU_ALPHA, scale, shift, resid.v if resid is not None else None, None)
+            self.layer_out.append(y)
             return y
 
         def feature_block(inp, reps, out_last=None):
@@ -264,7 +292,7 @@ class _Plan:
             li[0] += 1
             sp = specs[i]
             fm = self._new(N, src.h, src.w, D, Dld, zero=True)
-            self._emit(self.fwd, lib.y3_conv2d_fwd, src.v, ptr(sp.w_off), ptr(sp.b_off), 1, 1, fm.v, 0, 0.0, None, None, None, None)
+            self._conv_call(self.fwd, fm.m, sp, lib.y3_conv2d_fwd, src.v, ptr(sp.w_off), ptr(sp.b_off), 1, 1, fm.v, 0, 0.0, None, None, None, None)
             self.ops.append(('head', i, src, fm))
             return fm
 
@@ -323,6 +351,7 @@ class _Plan:
             f.gw = True
         if tr:
             self._build_backward()
+        self._bind_conv_workspace()
 
     # -- backward emission -------------------------------------------------------
     def _grad_of(self, t):
@@ -369,7 +398,8 @@ class _Plan:
                 self._emit(self.bwd, lib.y3_colsum, dfm.v, gptr(sp.b_off))
                 self._emit(self.bwd, lib.y3_conv2d_wgrad, src.v, dfm.v, 1, 1, gptr(sp.w_off), self.wg_ws.data_ptr(), self.wg_ws_bytes)
                 ds = self._grad_of(src)
-                self._emit(self.bwd, lib.y3_conv2d_dgrad, dfm.v, Wt.data_ptr() + 4 * sp.w_off, 1, 1, ds.v, EPI_ACCUM if src.gw else 0)
+                self._conv_call(self.bwd, ds.m, sp, lib.y3_conv2d_dgrad, dfm.v, Wt.data_ptr() + 4 * sp.w_off, 1, 1, ds.v, EPI_ACCUM if src.gw else 0,
+                                need=int(lib.y3_conv2d_dgrad_workspace(dfm.v, 1, 1, ds.v)))
                 src.mark_written()
                 self.bwd.append(('layer_done', i))
             elif kind == 'upsample':
@@ -395,7 +425,8 @@ class _Plan:
                 self._emit(self.bwd, lib.y3_conv2d_wgrad, src.v, dz.v, sp.k, sp.s, gptr(sp.w_off), self.wg_ws.data_ptr(), self.wg_ws_bytes)
                 if src is not first_src:
                     ds = self._grad_of(src)
-                    self._emit(self.bwd, lib.y3_conv2d_dgrad, dz.v, Wt.data_ptr() + 4 * sp.w_off, sp.k, sp.s, ds.v, EPI_ACCUM if src.gw else 0)
+                    self._conv_call(self.bwd, ds.m, sp, lib.y3_conv2d_dgrad, dz.v, Wt.data_ptr() + 4 * sp.w_off, sp.k, sp.s, ds.v,
+                                    EPI_ACCUM if src.gw else 0, need=int(lib.y3_conv2d_dgrad_workspace(dz.v, sp.k, sp.s, ds.v)))
                     src.mark_written()
                 self.bwd.append(('layer_done', i))
 

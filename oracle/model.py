@@ -180,6 +180,8 @@ class Net:
                 layer = cl(layer)
                 layer = cl(layer)
                 layer = inp + layer
+                if self.trace is not None:
+                    self.trace[-1] = layer.detach()      # the trace keeps what the next layer consumes
             return layer
 
         def yolo_block(inp):                        # model.py:51-59

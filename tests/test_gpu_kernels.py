@@ -43,6 +43,9 @@ CONV_CASES = [
     (2, 128, 128, 32, 128, 3, 1),   # 256 tiles of 128x128
     (1, 64, 64, 64, 32, 1, 1),      # BN=32 tile
     (3, 20, 20, 64, 64, 3, 1),      # BN=64 tile, M not a tile multiple
+    (8, 13, 13, 512, 1024, 3, 1),   # split-K (few tiles, K = 4608)
+    (8, 26, 26, 512, 256, 1, 1),    # split-K 1x1
+    (8, 13, 13, 256, 512, 3, 2),    # split-K, stride 2, odd input
 ]
 
 
@@ -65,9 +68,12 @@ def test_conv_fwd(hip, case):
     wd, bd = wk.contiguous().cuda(), b.cuda()
     src = hip.Tensor(sv.data_ptr(), n, h, w, cin, cin + 8)
     dst = hip.Tensor(dv.data_ptr(), n, oh, ow, cout, old)
-    tiles = hip.lib.y3_conv2d_stats_tiles(n * oh * ow, cout)
+    tiles = hip.lib.y3_conv2d_stats_tiles(n * oh * ow, cin, k, cout)
     stats = torch.full((tiles * 2 * cout,), float('nan'), device='cuda')
-    hip.check(hip.lib.y3_conv2d_fwd(src, wd.data_ptr(), bd.data_ptr(), k, s, dst, hip.EPI_LRELU, 0.2, None, None, None, stats.data_ptr(), stream()))
+    wsb = int(hip.lib.y3_conv2d_fwd_workspace(n * oh * ow, cin, k, cout))
+    ws = torch.empty(wsb // 4 + 4, device='cuda')
+    hip.check(hip.lib.y3_conv2d_fwd(src, wd.data_ptr(), bd.data_ptr(), k, s, dst, hip.EPI_LRELU, 0.2, None, None, None, stats.data_ptr(),
+                                    ws.data_ptr(), wsb, stream()))
     ref = F.leaky_relu(_conv_ref(x, wk, b, k, s), 0.2)
     assert_close(dv.cpu().permute(0, 3, 1, 2), ref, rtol=2e-5, what='conv fwd')
     st = stats.view(tiles, 2, cout).double().sum(0).cpu()
@@ -78,10 +84,11 @@ def test_conv_fwd(hip, case):
         assert torch.isnan(dbuf.view(-1, old)[:, cout:]).all()
 
 
-def test_conv_fwd_fused_inference_epilogue(hip):
-    """lrelu -> scale/shift -> + resid (inference-mode BN folded, model.py:38,47)."""
+@pytest.mark.parametrize('shape', [(2, 26, 26, 64, 128, 3, 1), (1, 13, 13, 512, 1024, 3, 1), (1, 13, 13, 1024, 512, 1, 1), (1, 26, 26, 1024, 256, 1, 1)])
+def test_conv_fwd_fused_inference_epilogue(hip, shape):
+    """lrelu -> scale/shift -> + resid (inference-mode BN folded, model.py:38,47); the small-M shapes take the split-K path."""
     from util import nhwc_buf, stream, assert_close
-    n, h, w, cin, cout, k, s = 2, 26, 26, 64, 128, 3, 1
+    n, h, w, cin, cout, k, s = shape
     g = torch.Generator().manual_seed(5)
     x = torch.randn(n, cin, h, w, generator=g)
     wk = torch.randn(k, k, cin, cout, generator=g) * 0.05
@@ -95,14 +102,18 @@ def test_conv_fwd_fused_inference_epilogue(hip):
     rv.copy_(r.permute(0, 2, 3, 1))
     _, dv = nhwc_buf(n, h, w, cout)
     wd, bd, scd, shd = wk.contiguous().cuda(), b.cuda(), sc.cuda(), sh.cuda()
+    wsb = int(hip.lib.y3_conv2d_fwd_workspace(n * h * w, cin, k, cout))
+    ws = torch.empty(wsb // 4 + 4, device='cuda')
     hip.check(hip.lib.y3_conv2d_fwd(hip.Tensor(sv.data_ptr(), n, h, w, cin, cin), wd.data_ptr(), bd.data_ptr(), k, s,
                                     hip.Tensor(dv.data_ptr(), n, h, w, cout, cout), hip.EPI_LRELU, 0.2, scd.data_ptr(), shd.data_ptr(),
-                                    hip.Tensor(rv.data_ptr(), n, h, w, cout, 2 * cout), None, stream()))
+                                    hip.Tensor(rv.data_ptr(), n, h, w, cout, 2 * cout), None, ws.data_ptr(), wsb, stream()))
     ref = F.leaky_relu(_conv_ref(x, wk, b, k, s), 0.2) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None] + r.double()
     assert_close(dv.cpu().permute(0, 3, 1, 2), ref, rtol=2e-5, what='fused epilogue')
 
 
 DGRAD_CASES = [
+    (8, 13, 13, 512, 1024, 3, 1),   # split-K
+    (8, 26, 26, 256, 512, 3, 2),    # split-K across the four parity launches
     (2, 13, 13, 64, 128, 3, 1),
     (2, 13, 13, 128, 64, 1, 1),
     (2, 26, 26, 32, 64, 3, 2),
@@ -138,15 +149,17 @@ def test_conv_dgrad(hip, case, accum):
     wd = wk.contiguous().cuda()
     hip.check(hip.lib.y3_transpose_weights(wd.data_ptr(), wt2.data_ptr(), k * k, cin, cout, stream()))
     assert torch.equal(wt, wt2)
-    hip.check(hip.lib.y3_conv2d_dgrad(hip.Tensor(ddv.data_ptr(), n, oh, ow, cout, cld), wt2.data_ptr(), k, s,
-                                      hip.Tensor(dsv.data_ptr(), n, h, w, cin, cin + 4), hip.EPI_ACCUM if accum else 0, stream()))
+    DD, DS = hip.Tensor(ddv.data_ptr(), n, oh, ow, cout, cld), hip.Tensor(dsv.data_ptr(), n, h, w, cin, cin + 4)
+    wsb = int(hip.lib.y3_conv2d_dgrad_workspace(DD, k, s, DS))
+    ws = torch.empty(wsb // 4 + 4, device='cuda')
+    hip.check(hip.lib.y3_conv2d_dgrad(DD, wt2.data_ptr(), k, s, DS, hip.EPI_ACCUM if accum else 0, ws.data_ptr(), wsb, stream()))
     ref = x.grad.permute(0, 2, 3, 1)
     if accum:
         ref = ref + init.double()
     assert_close(dsv.cpu(), ref, rtol=2e-5, what='dgrad')
 
 
-WGRAD_CASES = CONV_CASES[:6] + [(8, 52, 52, 128, 256, 1, 1), (2, 64, 64, 32, 64, 3, 2)]
+WGRAD_CASES = CONV_CASES[:6] + CONV_CASES[9:10] + [(8, 52, 52, 128, 256, 1, 1), (2, 64, 64, 32, 64, 3, 2)]
 
 
 @pytest.mark.parametrize('case', WGRAD_CASES)
@@ -302,7 +315,7 @@ def test_data_movement(hip):
 def test_errors_are_reported(hip):
     """Bad arguments return an error code and a message; nothing is launched."""
     t = hip.Tensor(0, 1, 1, 1, 4, 4)
-    rc = hip.lib.y3_conv2d_fwd(t, None, None, 3, 1, t, 0, 0.0, None, None, None, None, None)
+    rc = hip.lib.y3_conv2d_fwd(t, None, None, 3, 1, t, 0, 0.0, None, None, None, None, None, 0, None)
     assert rc == -1 and b'null' in hip.lib.y3_last_error()
     with pytest.raises(hip.HipError):
         hip.check(rc, 'y3_conv2d_fwd')
