@@ -738,13 +738,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(const WgradArg
     }
 }
 
-// dst[i] = sum_z slabs[z][i]   (float4; count multiple of 4 guaranteed by caller padding or tail loop)
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dst, long long count, int nslabs) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        float s = 0.f;
-        for (int z = 0; z < nslabs; ++z) s += slabs[(long long)z * count + i];
-        dst[i] = s;
+// dst[i] = sum_z slabs[z][i], fixed summation order (deterministic).  A block owns 64 consecutive outputs
+// (16 float4 lanes) x 16 slab lanes: the slab axis is parallel too, so a few-thousand-element gradient
+// split over ~1000 pixel chunks is not reduced by a handful of serial threads.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dst, long long count, int nslabs) {
+    __shared__ f32x4 sm[16][16];
+    const int cl = threadIdx.x & 15, zl = threadIdx.x >> 4;
+    const long long i = ((long long)blockIdx.x * 16 + cl) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (i < count)
+        for (int z = zl; z < nslabs; z += 16) acc += *reinterpret_cast<const f32x4*>(slabs + (long long)z * count + i);
+    sm[zl][cl] = acc;
+    __syncthreads();
+    if (zl == 0 && i < count) {
+#pragma unroll
+        for (int z = 1; z < 16; ++z) acc += sm[z][cl];
+        *reinterpret_cast<f32x4*>(dst + i) = acc;
     }
 }
 
@@ -1185,9 +1194,11 @@ static WgradPlan plan_wgrad(int K, int Nout, int M) {
     w.bkr = (K <= 64) ? 64 : 128;
     w.bn = (Nout <= 32) ? 32 : (Nout <= 64 ? 64 : 128);
     w.tiles = y3_cdiv(K, w.bkr) * y3_cdiv(Nout, w.bn);
-    // aim at ~4 workgroups per CU overall, at least 256 pixels per split
-    int splits = y3_cdiv(1024, w.tiles);
-    const int maxs = y3_cdiv(M, 256);
+    // aim at ~16 waves per CU overall (these launches are latency / HBM bound per workgroup), at least 128 pixels per split
+    static const int want_waves = env_int("Y3_WGRAD_WAVES", 4096);
+    const int waves_per_wg = (w.bkr == 64 && w.bn == 32) ? 2 : 4;
+    int splits = y3_cdiv(want_waves, w.tiles * waves_per_wg);
+    const int maxs = y3_cdiv(M, 128);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
     int chunk = y3_cdiv(M, splits);
@@ -1259,9 +1270,8 @@ extern "C" int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int 
         hipLaunchKernelGGL((conv_wgrad_kernel<64, 32, 2, 1, 16>), grid, dim3(128), 0, st, p);
     Y3_CHECK_LAUNCH("conv_wgrad");
     if (w.splits > 1) {
-        const long long count = (long long)p.K * p.Nout;
-        const int blocks = (int)((count + 255) / 256 > 2048 ? 2048 : (count + 255) / 256);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, count, w.splits);
+        const long long count = (long long)p.K * p.Nout;  // K*Nout is a multiple of 4 (Cin % 4 == 0)
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, st, (const float*)workspace, dw, count, w.splits);
         Y3_CHECK_LAUNCH("slab_reduce");
     }
     return Y3_OK;
