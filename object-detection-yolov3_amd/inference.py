@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""inference.py -- per image: z-score -> network -> clip -> small-box filter -> class-wise NMS -> X,Y,W,H,C csv.
+Reference: inference.py:24-135 (same flags).  --saved-model-filepath points at the weight file written by train.py
+(<output_dir>/saved_model/yolov3.npz) instead of a TF SavedModel.  Everything between reading the image and writing
+the csv runs on the GPU."""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from yolo3 import bbox_utils, imagereader
+from yolo3.model import YoloV3
+
+
+def load_model(path):
+    if os.path.isdir(path):
+        path = os.path.join(path, 'yolov3.npz')
+    return YoloV3.from_file(path)
+
+
+def inference(image_folder, image_format, saved_model_filepath, output_folder, min_box_size):
+    os.makedirs(output_folder, exist_ok=True)
+    if image_format.startswith('.'):
+        image_format = image_format[1:]
+    img_filepath_list = [os.path.join(image_folder, fn) for fn in os.listdir(image_folder) if fn.endswith('.{}'.format(image_format))]
+    yolo = load_model(saved_model_filepath)
+    yolo_model = yolo.get_keras_model()
+    print('Starting inference of file list')
+    for i, img_filepath in enumerate(img_filepath_list):
+        _, file_name = os.path.split(img_filepath)
+        print('{}/{} : {}'.format(i, len(img_filepath_list), file_name))
+        img = imagereader.imread(img_filepath)
+        if img.ndim == 2:
+            img = img[:, :, None]
+        height, width, channels = img.shape
+        x = torch.from_numpy(np.ascontiguousarray(img.astype(np.float32).transpose((2, 0, 1)))).cuda()[None]
+        x = imagereader.zscore_normalize_device(x)                       # whole-image statistics (inference.py:49)
+        rows = yolo_model(x, training=False)                              # [1, Nb, 5+K]
+        # clip to the image (the intent of inference.py:62-65, Q11), small-box filter (:72), class-wise NMS (:79)
+        boxes, scores, class_label, _ = bbox_utils.detect(rows, min_box_size, clip_wh=(width, height))[0]
+        if boxes is None:                                                 # the reference would crash here (Q11); write an empty csv
+            out = np.zeros((0, 5), np.int32)
+        else:
+            boxes[:, 2] = boxes[:, 2] - boxes[:, 0]
+            boxes[:, 3] = boxes[:, 3] - boxes[:, 1]
+            out = np.concatenate((boxes, class_label.reshape(-1, 1)), axis=-1).astype(np.int32)    # truncation (Q20)
+        print('Found: {} rois'.format(out.shape[0]))
+        bbox_utils.write_boxes_from_xywhc(out, os.path.join(output_folder, file_name.replace(image_format, 'csv')))
+
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser(prog='inference', description='Script to detect stars with the selected model')
+    parser.add_argument('--saved-model-filepath', type=str, help='Filepath to the saved model to use', required=True)
+    parser.add_argument('--output-folder', type=str, required=True)
+    parser.add_argument('--image-folder', dest='image_folder', type=str, required=True)
+    parser.add_argument('--image-format', dest='image_format', type=str, default='tif')
+    parser.add_argument('--min-box-size', type=int, default=32, help='Smallest detection to consider. Default (32, 32).')
+    a = parser.parse_args()
+    print('Arguments:')
+    for k, v in vars(a).items():
+        print('{} = {}'.format(k, v))
+    inference(a.image_folder, a.image_format, a.saved_model_filepath, a.output_folder, a.min_box_size)

@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""inference_tiled.py -- large image -> overlapping tiles (96-px ghost border, reflect padding) -> network + NMS per
+tile -> ghost-band rejection -> global merge -> X,Y,W,H,P,C csv.  Reference: inference_tiled.py:29-382 (same flags).
+
+The tile geometry and the merge rules are the reference's, including Q12 (tiles that were reflect-padded on the
+left / top report their clamped origin).  Unlike the reference (one tile per model call, BATCH_SIZE unused at :25) the
+tiles of an image go through the network in batches, are z-scored per tile and NMS'ed on the GPU in one launch per
+batch."""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from yolo3 import bbox_utils, imagereader
+from yolo3.model import YoloV3
+
+BATCH_SIZE = 8
+EDGE_EFFECT_RANGE = 96            # inference_tiled.py:26
+NETWORK_DOWNSAMPLE_FACTOR = 32
+
+
+def convert_image_to_tiles(img, tile_size):
+    """inference_tiled.py:29-100 -> (tiles, x origins, y origins)."""
+    height, width = img.shape[0], img.shape[1]
+    radius = [EDGE_EFFECT_RANGE, EDGE_EFFECT_RANGE]
+    assert tile_size[0] % NETWORK_DOWNSAMPLE_FACTOR == 0 and tile_size[1] % NETWORK_DOWNSAMPLE_FACTOR == 0
+    if tile_size[0] >= height:
+        radius[0] = 0
+    if tile_size[1] >= width:
+        radius[1] = 0
+    zone = [tile_size[0] - 2 * radius[0], tile_size[1] - 2 * radius[1]]
+    tiles, xs, ys = [], [], []
+    for i in range(0, height, zone[0]):
+        for j in range(0, width, zone[1]):
+            x_st, y_st = j - radius[1], i - radius[0]
+            x_end, y_end = j + zone[1] + radius[1], i + zone[0] + radius[0]
+            pre_x, pre_y = max(-x_st, 0), max(-y_st, 0)
+            x_st, y_st = max(x_st, 0), max(y_st, 0)
+            post_x, post_y = max(x_end - width, 0), max(y_end - height, 0)
+            x_end, y_end = min(x_end, width), min(y_end, height)
+            tile = img[y_st:y_end, x_st:x_end]
+            if pre_x or post_x or pre_y or post_y:
+                tile = np.pad(tile, pad_width=((pre_y, post_y), (pre_x, post_x), (0, 0)), mode='reflect')
+            xs.append(x_st)          # the CLAMPED origin (Q12)
+            ys.append(y_st)
+            tiles.append(tile)
+    return tiles, xs, ys
+
+
+def merge_tile_detections(boxes, scores, class_label, tile_x, tile_y, tile_size, img_size):
+    """Ghost-band rejection + shift to global coordinates for one tile (inference_tiled.py:230-266).
+    boxes float32 [M,4] x1,y1,x2,y2 in tile coordinates.  Returns (boxes, scores, labels) or None."""
+    scores = scores.reshape((-1, 1))
+    class_label = class_label.reshape((-1, 1))
+    cx = (boxes[:, 2] + boxes[:, 0]) / 2.0
+    cy = (boxes[:, 3] + boxes[:, 1]) / 2.0
+    cxg, cyg = cx + tile_x, cy + tile_y
+    E = EDGE_EFFECT_RANGE
+    invalid = ((cyg > E) & (cy < E)) | ((cyg <= img_size[0] - E) & (cy >= tile_size[0] - E)) | \
+              ((cxg > E) & (cx < E)) | ((cxg <= img_size[1] - E) & (cx >= tile_size[1] - E))
+    if np.any(invalid):
+        boxes, scores, class_label = boxes[~invalid, :], scores[~invalid], class_label[~invalid]
+    if boxes.shape[0] == 0:
+        return None
+    boxes = boxes.copy()
+    boxes[:, 0] += tile_x
+    boxes[:, 2] += tile_x
+    boxes[:, 1] += tile_y
+    boxes[:, 3] += tile_y
+    return boxes, scores, class_label
+
+
+def finalize_predictions(boxes_list, scores_list, class_label_list, img_size):
+    """inference_tiled.py:272-310: concat, round, drop centres outside the image, clamp -> float64 [M,6]."""
+    if len(boxes_list) > 0:
+        boxes = np.round(np.concatenate(boxes_list, axis=0)).astype(np.int32)
+        scores = np.concatenate(scores_list, axis=0)
+        class_label = np.concatenate(class_label_list, axis=0)
+        cx = (boxes[:, 2] + boxes[:, 0]) / 2.0
+        cy = (boxes[:, 3] + boxes[:, 1]) / 2.0
+        invalid = (cx < 0) | (cx >= img_size[1]) | (cy < 0) | (cy >= img_size[0])
+        if np.any(invalid):
+            boxes, scores, class_label = boxes[~invalid, :], scores[~invalid], class_label[~invalid]
+        for col, lim in ((0, img_size[1]), (1, img_size[0]), (2, img_size[1]), (3, img_size[0])):
+            boxes[boxes[:, col] < 0, col] = 0
+            boxes[boxes[:, col] >= lim, col] = lim - 1
+    else:
+        boxes, scores, class_label = np.zeros((0, 4)), np.zeros((0, 1)), np.zeros((0, 1))
+    return np.concatenate((boxes, scores, class_label), axis=-1)
+
+
+def inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size=BATCH_SIZE):
+    """inference_tiled.py:185-310.  ``yolo_model(batch, training=False)`` maps CUDA float32 [B,C,h,w] (z-scored) to
+    rows [B, Nb, 5+K] (CUDA tensor or ndarray)."""
+    img_size = img.shape
+    tiles, xs, ys = convert_image_to_tiles(img, tile_size)
+    boxes_list, scores_list, class_label_list = [], [], []
+    for b0 in range(0, len(tiles), batch_size):
+        chunk = tiles[b0:b0 + batch_size]
+        x = torch.from_numpy(np.stack([t.astype(np.float32).transpose((2, 0, 1)) for t in chunk])).cuda()
+        x = imagereader.zscore_normalize_device(x)                       # per TILE statistics (inference_tiled.py:205, Q12)
+        rows = yolo_model(x, training=False)
+        rows = torch.as_tensor(rows, dtype=torch.float32).cuda()
+        dets = bbox_utils.detect(rows, min_roi_size)
+        for k, (boxes, scores, class_label, _) in enumerate(dets):
+            if boxes is None:
+                continue
+            r = merge_tile_detections(boxes, scores, class_label, xs[b0 + k], ys[b0 + k], tile_size, img_size)
+            if r is not None:
+                boxes_list.append(r[0])
+                scores_list.append(r[1])
+                class_label_list.append(r[2])
+    predictions = finalize_predictions(boxes_list, scores_list, class_label_list, img_size)
+    print('Found: {} rois'.format(predictions.shape[0]))
+    return predictions
+
+
+def inference_image_folder(image_folder, image_format, saved_model_filepath, output_folder, tile_size, min_roi_size):
+    if not os.path.exists(saved_model_filepath):
+        raise RuntimeError('Missing saved_model_filepath File')
+    if image_format.startswith('.'):
+        image_format = image_format[1:]
+    img_filepath_list = [os.path.join(image_folder, fn) for fn in os.listdir(image_folder) if fn.endswith('.{}'.format(image_format))]
+    path = os.path.join(saved_model_filepath, 'yolov3.npz') if os.path.isdir(saved_model_filepath) else saved_model_filepath
+    yolo = YoloV3.from_file(path)
+    if list(tile_size) != list(yolo.img_size[:2]):
+        raise RuntimeError('tile size {} must equal the size the model was trained at {} (Q18)'.format(tile_size, yolo.img_size[:2]))
+    yolo_model = yolo.get_keras_model()
+    os.makedirs(output_folder, exist_ok=True)
+    print('Starting inference of file list')
+    for i, img_filepath in enumerate(img_filepath_list):
+        _, file_name = os.path.split(img_filepath)
+        print('{}/{} : {}'.format(i, len(img_filepath_list), file_name))
+        img = imagereader.imread(img_filepath)
+        if len(img.shape) == 2:
+            img = np.expand_dims(img, -1)
+        predictions = inference_image_tiled(yolo_model, img, tile_size, min_roi_size)
+        bbox_utils.write_boxes_from_ltrbpc(predictions, os.path.join(output_folder, file_name.replace(image_format, 'csv')))
+
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser(prog='inference', description='Script to detect stars with the selected model')
+    parser.add_argument('--saved-model-filepath', type=str, required=True)
+    parser.add_argument('--output-folder', type=str, required=True)
+    parser.add_argument('--image-folder', dest='image_folder', type=str, required=True)
+    parser.add_argument('--image-format', dest='image_format', type=str, default='tif')
+    parser.add_argument('--tile-height', type=int, default=512)
+    parser.add_argument('--tile-width', type=int, default=512)
+    parser.add_argument('--min-box-size', type=int, default=32)
+    a = parser.parse_args()
+    inference_image_folder(a.image_folder, a.image_format, a.saved_model_filepath, a.output_folder, [a.tile_height, a.tile_width], a.min_box_size)

@@ -107,6 +107,26 @@ def filter_small_boxes(boxes, min_size):
     return boxes[np.logical_and(w > min_size, h > min_size), :]
 
 
+def load_boxes_to_xywhc(filepath):
+    """bbox_utils.py:106-124: CSV with header X,Y,W,H,C (skipinitialspace) -> float [n,5]; missing file -> [0,5]."""
+    import csv
+    import os
+    rows = []
+    if os.path.exists(filepath):
+        with open(filepath) as fh:
+            for row in csv.DictReader(fh, skipinitialspace=True):
+                rows.append([int(row['X']), int(row['Y']), int(row['W']), int(row['H']), int(row['C'])])
+    return np.asarray(rows, dtype=np.float64).reshape(-1, 5)
+
+
+def load_boxes_to_ltrbc(filepath):
+    """bbox_utils.py:83-103: as above with W,H converted to inclusive right / bottom."""
+    a = load_boxes_to_xywhc(filepath)
+    a[:, 2] = a[:, 0] + a[:, 2] - 1
+    a[:, 3] = a[:, 1] + a[:, 3] - 1
+    return a
+
+
 def write_boxes_from_xywhc(boxes, csv_filename):
     """bbox_utils.py:47-62."""
     with open(csv_filename, 'w') as fh:

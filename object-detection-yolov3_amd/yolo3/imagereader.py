@@ -2,15 +2,25 @@
 contract: z-score normalisation (GPU kernel), HWC->CHW formatting and the
 ground-truth label layout the loss consumes.
 
+ImageReader       imagereader.py:79-460  (lmdb + protobuf datasets, worker processes, bounded queue)
 zscore_normalize  imagereader.py:34-46   (csrc/pointwise.hip, fp64 partial sums)
 format_image      imagereader.py:57-60
 format_boxes      ImageReader.__format_boxes, imagereader.py:252-324 (host NumPy,
                   as in the reference: it runs in the reader processes)
 """
+import multiprocessing
+import os
+import queue
+import random
+import traceback
+
 import numpy as np
 import torch
 
 from ._hip import lib, check
+from . import augment
+from . import lmdbio
+from .isg_ai_pb import ImageYoloBoxesPair
 
 NETWORK_DOWNSAMPLE_FACTOR = 32   # model.YoloV3.NETWORK_DOWNSAMPLE_FACTOR (model.py:25)
 
@@ -73,3 +83,221 @@ def format_boxes(boxes, image_size, anchors, number_classes):
             label[l][i, j, n, 4] = 1.0
             label[l][i, j, n, 5 + c] = 1.0
     return label
+
+
+def imread(fp):
+    """imagereader.py:49-50 (skimage.io.imread there; PIL here).  Returns HWC or HW ndarray."""
+    from PIL import Image
+    return np.asarray(Image.open(fp))
+
+
+def imwrite(img, fp):
+    from PIL import Image
+    Image.fromarray(np.asarray(img)).save(fp)
+
+
+def _loader_process(reader, worker_id):
+    reader._image_loader(worker_id)
+
+
+class Dataset:
+    """What get_tf_dataset() hands out: an iterable of (image[C,H,W], label_1, label_2, label_3); ``batch(n)`` stacks
+    n examples and moves them to the GPU, where the images are z-scored by the HIP kernel (the reference z-scores in
+    the reader processes on the CPU, imagereader.py:398)."""
+
+    def __init__(self, reader, batch_size=None, device=None):
+        self.reader, self.batch_size, self.device = reader, batch_size, device
+
+    def batch(self, n):
+        return Dataset(self.reader, int(n), self.device)
+
+    def prefetch(self, n):            # the bounded worker queue already prefetches (train.py:61)
+        return self
+
+    def shard(self, num_shards, index):   # experimental_distribute_dataset: each replica reads its own examples
+        return self
+
+    def __iter__(self):
+        gen = self.reader.generator()
+        if self.batch_size is None:
+            yield from gen
+            return
+        dev = self.device or torch.device('cuda', torch.cuda.current_device())
+        while True:
+            ex = []
+            for e in gen:
+                ex.append(e)
+                if len(ex) == self.batch_size:
+                    break
+            if len(ex) < self.batch_size:
+                return
+            imgs = torch.from_numpy(np.stack([e[0] for e in ex])).to(dev, non_blocking=True)
+            imgs = zscore_normalize_device(imgs)
+            labels = [torch.from_numpy(np.stack([e[i] for e in ex])).to(dev, non_blocking=True) for i in (1, 2, 3)]
+            yield (imgs, *labels)
+
+
+class ImageReader:
+    """imagereader.ImageReader (imagereader.py:79-460): same constructor, startup / shutdown / get_image_size /
+    get_number_classes / get_image_count / get_example / generator; get_tf_dataset() returns a ``Dataset``."""
+
+    def __init__(self, img_db, anchors, use_augmentation=True, balance_classes=False, shuffle=True, num_workers=1):
+        self.image_db = img_db
+        self.use_augmentation = use_augmentation
+        self.queue_starvation = False
+        self.balance_classes = balance_classes
+        self.anchors = anchors
+        self.number_anchors = len(anchors)
+        if not os.path.exists(self.image_db):
+            print('Could not load database file: ')
+            print(self.image_db)
+            raise Exception("Missing Database")
+        self.shuffle = shuffle
+        random.seed()
+        self.keys_flat = []
+        self.keys = [[]]
+        env = lmdbio.Environment(self.image_db)
+        all_keys = list(env.keys())
+        empty_images_flag = False
+        highest = 0
+        for key in all_keys:                                      # key = "<n>_<name>:<c0,c1,...>" (build_lmdb.py:90-96)
+            for k in key.decode('ascii').split(':')[1].split(','):
+                if len(k) == 0:
+                    empty_images_flag = True
+                else:
+                    highest = max(highest, int(k))
+        for _ in range(highest):
+            self.keys.append([])
+        if empty_images_flag:
+            self.keys.append([])
+        for key in all_keys:
+            self.keys_flat.append(key)
+            for k in key.decode('ascii').split(':')[1].split(','):
+                idx = 0 if len(k) == 0 else (int(k) + 1 if empty_images_flag else int(k))
+                self.keys[idx].append(key)
+        datum = ImageYoloBoxesPair().ParseFromString(env.get(self.keys_flat[0]))
+        self.image_size = [datum.img_height, datum.img_width, datum.channels]
+        env.close()
+        self.number_classes = len(self.keys) - 1 if empty_images_flag else len(self.keys)
+        print('Found images of shape: {}'.format(self.image_size))
+        print('Dataset has {} examples'.format(len(self.keys_flat)))
+        self.nb_workers = num_workers
+        self.maxOutQSize = num_workers * 10
+        ctx = multiprocessing.get_context('fork')
+        self._ctx = ctx
+        self.terminateQ = ctx.Queue(maxsize=self.nb_workers)
+        self.outQ = ctx.Queue(maxsize=self.maxOutQSize)
+        self.workers = None
+        self.done = False
+
+    def get_image_size(self):
+        return self.image_size
+
+    def get_number_classes(self):
+        return self.number_classes
+
+    def get_image_count(self):
+        return int(len(self.keys_flat))
+
+    def startup(self):
+        self.done = False
+        self.workers = [self._ctx.Process(target=_loader_process, args=(self, i), daemon=True) for i in range(self.nb_workers)]
+        for w in self.workers:
+            w.start()
+
+    def shutdown(self):
+        if not self.workers:
+            return
+        for _ in self.workers:
+            self.terminateQ.put(None)
+        got = 0
+        while got < len(self.workers):                      # drain so blocked workers can finish (imagereader.py:203-222)
+            try:
+                while True:
+                    if self.outQ.get(timeout=0.2) is None:
+                        got += 1
+            except queue.Empty:
+                if not any(w.is_alive() for w in self.workers):
+                    break
+        for w in self.workers:
+            w.join(5)
+        self.workers = None
+
+    def _next_key(self, state):
+        if self.shuffle:
+            if self.balance_classes:                            # imagereader.py:226-240
+                while True:
+                    label_idx = random.randint(0, len(self.keys) - 1)
+                    if len(self.keys[label_idx]) > 0:
+                        break
+                return self.keys[label_idx][random.randint(0, len(self.keys[label_idx]) - 1)]
+            return self.keys_flat[random.randint(0, len(self.keys_flat) - 1)]
+        fn = self.keys_flat[state['idx']]                     # no shuffle: stride the flat key list by worker id (Q17)
+        state['idx'] = (state['idx'] + self.nb_workers) % len(self.keys_flat)
+        return fn
+
+    def load_example(self, key, env):
+        """One example as the workers produce it: (image[C,H,W] float32 NOT yet z-scored, label_1, label_2, label_3)."""
+        datum = ImageYoloBoxesPair().ParseFromString(env.get(key))
+        img, boxes = datum.to_arrays()
+        if list(img.shape) != list(self.image_size):
+            raise RuntimeError("Encountered unexpected image shape from database. Expected {}. Found {}.".format(self.image_size, img.shape))
+        boxes = boxes.copy()
+        crop_to = [self.image_size[0], self.image_size[1]]
+        if self.use_augmentation:                               # severities of imagereader.py:369-391
+            img, boxes = augment.augment_image_box_pair(img.astype(np.float32), boxes, reflection_flag=True, rotation_flag=False, crop_to=crop_to,
+                                                        noise_augmentation_severity=0.03, scale_augmentation_severity=0.1,
+                                                        blur_augmentation_max_sigma=2, box_size_augmentation_severity=0.03,
+                                                        box_location_jitter_severity=0.03)
+        if img.shape[0] != self.image_size[0] or img.shape[1] != self.image_size[1]:
+            img, boxes = augment.crop_to_size(img, boxes, crop_to)
+        img = np.ascontiguousarray(format_image(img)).astype(np.float32)
+        labels = format_boxes(boxes, self.image_size, self.anchors, self.number_classes)
+        return (img, labels[0], labels[1], labels[2])
+
+    def _image_loader(self, worker_id):
+        state = {'idx': worker_id}
+        try:
+            random.seed()
+            np.random.seed((os.getpid() * 2654435761) % (2 ** 32))
+            env = lmdbio.Environment(self.image_db)
+            while True:
+                try:
+                    if self.terminateQ.get_nowait() is None:
+                        break
+                except queue.Empty:
+                    pass
+                self.outQ.put(self.load_example(self._next_key(state), env))
+        except Exception as e:                                  # imagereader.py:413-417
+            print('***************** Reader Error *****************')
+            print(e)
+            traceback.print_exc()
+            print('***************** Reader Error *****************')
+        finally:
+            self.outQ.put(None)
+
+    def get_example(self):
+        if self.outQ.qsize() < int(0.1 * self.maxOutQSize):     # imagereader.py:424-430
+            if not self.queue_starvation:
+                print('Input Queue Starvation !!!!')
+            self.queue_starvation = True
+        if self.queue_starvation and self.outQ.qsize() > int(0.5 * self.maxOutQSize):
+            print('Input Queue Starvation Over')
+            self.queue_starvation = False
+        return self.outQ.get()
+
+    def generator(self):
+        while True:
+            example = self.get_example()
+            if example is None:
+                return
+            yield example
+
+    def get_queue_size(self):
+        return self.outQ.qsize()
+
+    def get_tf_dataset(self):
+        """imagereader.py:443-460 (a torch-side iterable instead of tf.data)."""
+        return Dataset(self)
+
+    get_dataset = get_tf_dataset

@@ -1,0 +1,165 @@
+"""CPU-only tests of the data plane and CLI host logic: protobuf codec vs bytes serialised by the reference's own
+generated module, the LMDB reader/writer (round trips: parity with liblmdb is unpinned, none is available), the
+ImageReader surface, tiling / tiled-merge host code vs goldens produced by the reference's inference_tiled.py."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+
+def test_protobuf_codec_matches_reference_bytes(golden_dir):
+    from yolo3.isg_ai_pb import ImageYoloBoxesPair
+    z = np.load(os.path.join(golden_dir, 'proto_pair.npz'))
+    assert ImageYoloBoxesPair.from_arrays(z['img'], z['boxes']).SerializeToString() == z['msg'].tobytes()
+    assert ImageYoloBoxesPair.from_arrays(z['img1'], None).SerializeToString() == z['msg1'].tobytes()
+    m = ImageYoloBoxesPair().ParseFromString(z['msg'].tobytes())
+    img, boxes = m.to_arrays()
+    assert np.array_equal(img, z['img']) and np.array_equal(boxes, z['boxes'])
+    assert (m.channels, m.img_height, m.img_width, m.box_count, m.img_type, m.box_type) == (3, 6, 5, 2, '|u1', '<i4')
+    m1 = ImageYoloBoxesPair().ParseFromString(z['msg1'].tobytes())
+    img1, boxes1 = m1.to_arrays()
+    assert np.array_equal(img1, z['img1']) and boxes1.shape == (0, 5)
+
+
+@pytest.mark.parametrize('n,vsize', [(0, 0), (1, 10), (50, 100), (3000, 40), (40, 20000), (700, 5000)])
+def test_lmdb_round_trip(tmp_path, n, vsize):
+    """Leaf-only, multi-level branch trees and overflow values; ordered iteration and point lookups."""
+    from yolo3 import lmdbio
+    rng = np.random.default_rng(n + vsize)
+    items = {('%d_img%04d:%s' % (i, i, '0,1' if i % 3 else '')).encode(): rng.integers(0, 256, vsize + (i % 7), dtype=np.uint8).tobytes() for i in range(n)}
+    path = str(tmp_path / 'db.lmdb')
+    assert lmdbio.write_environment(path, items.items()) == n
+    assert os.path.exists(os.path.join(path, 'data.mdb')) and os.path.exists(os.path.join(path, 'lock.mdb'))
+    with lmdbio.Environment(path) as env:
+        assert env.stat()['entries'] == n
+        keys = list(env.keys())
+        assert keys == sorted(items)                  # LMDB's bytewise order: b'10_...' < b'2_...'
+        got = dict(env.items())
+        assert got == items
+        for k in list(items)[::max(1, n // 17)]:
+            assert env.get(k) == items[k]
+        assert env.get(b'missing') is None
+        if n >= 700:
+            assert env.stat()['depth'] >= 2
+
+
+def test_lmdb_rejects_garbage(tmp_path):
+    from yolo3 import lmdbio
+    p = tmp_path / 'x.lmdb'
+    p.mkdir()
+    (p / 'data.mdb').write_bytes(b'\0' * 8192)
+    with pytest.raises(lmdbio.LmdbError):
+        lmdbio.Environment(str(p))
+    with pytest.raises(lmdbio.LmdbError):
+        lmdbio.Environment(str(tmp_path / 'nope'))
+
+
+def _make_db(tmp_path, n=12, size=(64, 64, 3), K=2, with_empty=True, seed=3):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'object-detection-yolov3_amd'))
+    import build_lmdb
+    from yolo3 import lmdbio
+    rng = np.random.default_rng(seed)
+    items, truth = [], {}
+    for i in range(n):
+        img = rng.integers(0, 256, size, dtype=np.uint8)
+        k = 0 if (with_empty and i % 5 == 4) else int(rng.integers(1, 4))
+        wh = rng.integers(12, 40, (k, 2))
+        xy = np.stack([rng.integers(0, size[1] - wh[:, 0]), rng.integers(0, size[0] - wh[:, 1])], 1) if k else np.zeros((0, 2), int)
+        boxes = np.concatenate([xy, wh, rng.integers(0, K, (k, 1))], 1).astype(np.int32)
+        key, val = build_lmdb.make_record(img, boxes, i, 'img%03d' % i)
+        items.append((key, val))
+        truth[key] = (img, boxes)
+    path = str(tmp_path / 'train-x.lmdb')
+    lmdbio.write_environment(path, items)
+    return path, truth
+
+
+def test_image_reader_surface(tmp_path):
+    """ImageReader (imagereader.py:79-460): key parsing, class bookkeeping, example formatting, worker processes."""
+    from yolo3.imagereader import ImageReader, format_boxes
+    anchors = [(64, 384), (384, 64)]
+    path, truth = _make_db(tmp_path)
+    rd = ImageReader(path, anchors, use_augmentation=False, shuffle=False, num_workers=2)
+    assert rd.get_image_size() == [64, 64, 3] and rd.get_image_count() == 12
+    assert rd.get_number_classes() == 2               # classes 0/1 plus the bucket of box-free images
+    assert len(rd.keys) == 3 and sum(len(k) for k in rd.keys) >= 12
+    assert rd.keys_flat == sorted(truth)              # lmdb key order
+    from yolo3 import lmdbio
+    with lmdbio.Environment(path) as env:
+        key = rd.keys_flat[3]
+        img, l1, l2, l3 = rd.load_example(key, env)
+    timg, tboxes = truth[key]
+    assert img.dtype == np.float32 and img.shape == (3, 64, 64) and np.array_equal(img, timg.transpose(2, 0, 1).astype(np.float32))
+    want = format_boxes(tboxes.copy(), (64, 64, 3), anchors, 2)
+    assert all(np.array_equal(a, b) for a, b in zip((l1, l2, l3), want))
+    assert l1.shape == (2, 2, 2, 7) and l3.shape == (8, 8, 2, 7)
+    # worker processes + bounded queue + orderly shutdown
+    rd.startup()
+    gen = rd.generator()
+    seen = [next(gen) for _ in range(7)]
+    assert all(s[0].shape == (3, 64, 64) for s in seen)
+    rd.shutdown()
+    with pytest.raises(Exception):
+        ImageReader(str(tmp_path / 'absent.lmdb'), anchors)
+
+
+def test_image_reader_augmentation_keeps_contract(tmp_path):
+    from yolo3.imagereader import ImageReader
+    from yolo3 import lmdbio
+    path, truth = _make_db(tmp_path, n=6, size=(96, 96, 1), with_empty=False, seed=9)
+    rd = ImageReader(path, [(64, 384), (384, 64)], use_augmentation=True, shuffle=True, balance_classes=True, num_workers=1)
+    np.random.seed(0)
+    with lmdbio.Environment(path) as env:
+        for key in rd.keys_flat * 3:
+            img, l1, l2, l3 = rd.load_example(key, env)
+            assert img.shape == (1, 96, 96) and img.dtype == np.float32 and np.isfinite(img).all()
+            assert l1.shape == (3, 3, 2, 7) and l3.shape == (12, 12, 2, 7)
+            on = l3[..., 4] > 0
+            assert (l3[on][:, 2:4] > 0).all()
+
+
+def test_convert_image_to_tiles_matches_reference(golden_dir):
+    import inference_tiled
+    j = json.load(open(os.path.join(golden_dir, 'tiles.json')))
+    for name, g in j.items():
+        h, w, c = g['shape']
+        img = np.random.default_rng(g['seed']).integers(0, 256, (h, w, c), dtype=np.uint8)
+        tiles, xs, ys = inference_tiled.convert_image_to_tiles(img, g['tile'])
+        assert xs == g['x'] and ys == g['y'], name
+        assert [list(t.shape) for t in tiles] == g['tile_shapes'], name
+        assert [int(t.astype(np.int64).sum()) for t in tiles] == g['sums'], name
+        assert [t[0:2, 0:2, 0].astype(int).tolist() for t in tiles] == g['corner'], name
+
+
+def test_tiled_merge_matches_reference(golden_dir):
+    """Ghost-band rejection, global shift, rounding and clamping (inference_tiled.py:230-310) against the reference
+    run end to end with a deterministic fake model; the per-tile NMS comes from the oracle here (GPU twin: test_gpu_cli.py)."""
+    import inference_tiled
+    from oracle import nms as onms
+    z = np.load(os.path.join(golden_dir, 'tiled_e2e.npz'))
+    img_shape, tile = tuple(int(v) for v in z['img_shape']), [int(v) for v in z['tile']]
+    tiles, xs, ys = inference_tiled.convert_image_to_tiles(np.zeros(img_shape, np.uint8), tile)
+    assert len(tiles) == z['model_rows'].shape[0]
+    bl, sl, cl = [], [], []
+    for i, rows in enumerate(z['model_rows']):
+        f = onms.filter_small_boxes(rows, int(z['min_roi']))
+        b, s, l = onms.per_class_nms(f[:, 0:4], f[:, 4:5], f[:, 5:])
+        if b is None:
+            continue
+        r = inference_tiled.merge_tile_detections(b, s, l, xs[i], ys[i], tile, img_shape)
+        if r is not None:
+            bl.append(r[0]); sl.append(r[1]); cl.append(r[2])
+    pred = inference_tiled.finalize_predictions(bl, sl, cl, img_shape)
+    assert pred.shape == z['pred'].shape and np.array_equal(pred, z['pred'])
+
+
+def test_load_boxes_csv(tmp_path):
+    from yolo3 import bbox_utils
+    p = tmp_path / 'a.csv'
+    p.write_text('X, Y, W, H, C\n1, 2, 3, 4, 0\n10,20,30,40,1\n')
+    a = bbox_utils.load_boxes_to_xywhc(str(p))
+    assert a.tolist() == [[1, 2, 3, 4, 0], [10, 20, 30, 40, 1]]
+    assert bbox_utils.load_boxes_to_ltrbc(str(p)).tolist() == [[1, 2, 3, 5, 0], [10, 20, 39, 59, 1]]
+    assert bbox_utils.load_boxes_to_xywhc(str(tmp_path / 'none.csv')).shape == (0, 5)

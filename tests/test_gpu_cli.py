@@ -1,0 +1,119 @@
+"""GPU tests of the caller-level rows: tiled inference end to end against the reference's
+golden, and the three CLIs run as programs on a synthetic lmdb (train -> checkpoint -> export -> inference ->
+tiled inference)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'object-detection-yolov3_amd')
+
+
+def test_tiled_inference_matches_reference_golden(golden_dir):
+    """inference_image_tiled (tiles -> per-tile GPU z-score -> model -> GPU NMS -> ghost-band merge) with the same
+    deterministic fake model the reference was run with: the [M,6] prediction array must be IDENTICAL."""
+    import inference_tiled
+    z = np.load(os.path.join(golden_dir, 'tiled_e2e.npz'))
+    rows = z['model_rows']
+
+    class Fake:
+        i = 0
+
+        def __call__(self, batch, training=False):
+            assert batch.is_cuda and batch.shape[1:] == (1, 608, 608)
+            out = rows[self.i:self.i + batch.shape[0]]
+            self.i += batch.shape[0]
+            return torch.from_numpy(out).cuda()
+
+    img = np.random.default_rng(30).integers(0, 256, tuple(int(v) for v in z['img_shape']), dtype=np.uint8)
+    for bs in (1, 5):
+        fm = Fake()
+        pred = inference_tiled.inference_image_tiled(fm, img, [608, 608], int(z['min_roi']), batch_size=bs)
+        assert fm.i == rows.shape[0]
+        assert pred.dtype == np.float64 and np.array_equal(pred, z['pred'])
+
+
+def _write_dataset(tmp, n, size, K=2, seed=5):
+    sys.path.insert(0, PKG)
+    import build_lmdb
+    from yolo3 import lmdbio
+    rng = np.random.default_rng(seed)
+    for split, cnt in (('train', n), ('test', max(2, n // 3))):
+        items = []
+        for i in range(cnt):
+            img = rng.integers(0, 256, size, dtype=np.uint8)
+            k = int(rng.integers(1, 4))
+            wh = rng.integers(40, 120, (k, 2))
+            xy = np.stack([rng.integers(0, size[1] - wh[:, 0]), rng.integers(0, size[0] - wh[:, 1])], 1)
+            boxes = np.concatenate([xy, wh, rng.integers(0, K, (k, 1))], 1).astype(np.int32)
+            items.append(build_lmdb.make_record(img, boxes, i, 'img%03d' % i))
+        lmdbio.write_environment(os.path.join(tmp, '%s-syn.lmdb' % split), items)
+
+
+def test_cli_train_then_inference(tmp_path):
+    from PIL import Image
+    tmp = str(tmp_path)
+    size = (256, 256, 3)
+    _write_dataset(tmp, 8, size)
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    out = os.path.join(tmp, 'out')
+    r = subprocess.run([sys.executable, os.path.join(PKG, 'train.py'), '--batch_size', '2', '--test_every_n_steps', '3', '--train_database',
+                        os.path.join(tmp, 'train-syn.lmdb'), '--test_database', os.path.join(tmp, 'test-syn.lmdb'), '--output_dir', out,
+                        '--early_stopping', '1', '--use_augmentation', '1', '--max_epochs', '2', '--learning_rate', '1e-4'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'Performing Adam Optimizer learning rate warmup for 3 steps' in r.stdout
+    assert r.stdout.count('Train Epoch 0: Batch') == 4            # "step > N: break" runs N+1 steps (Q16)
+    losses = [float(v) for v in open(os.path.join(out, 'test_loss.csv')).read().split()]
+    assert len(losses) >= 1 and all(np.isfinite(losses))
+    model_file = os.path.join(out, 'saved_model', 'yolov3.npz')
+    assert os.path.exists(model_file) and os.path.exists(os.path.join(out, 'checkpoint', 'ckpt.npz'))
+
+    # inference.py on a folder of images of the training size
+    img_dir, det_dir = os.path.join(tmp, 'imgs'), os.path.join(tmp, 'dets')
+    os.makedirs(img_dir)
+    rng = np.random.default_rng(1)
+    for i in range(2):
+        Image.fromarray(rng.integers(0, 256, size, dtype=np.uint8)).save(os.path.join(img_dir, 'a%d.png' % i))
+    r = subprocess.run([sys.executable, os.path.join(PKG, 'inference.py'), '--saved-model-filepath', os.path.join(out, 'saved_model'),
+                        '--output-folder', det_dir, '--image-folder', img_dir, '--image-format', 'png', '--min-box-size', '8'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    for i in range(2):
+        lines = open(os.path.join(det_dir, 'a%d.csv' % i)).read().splitlines()
+        assert lines[0] == 'X,Y,W,H,C'
+        for ln in lines[1:]:
+            x, y, w, h, c = (int(v) for v in ln.split(','))
+            assert 0 <= x <= 256 and 0 <= y <= 256 and w > 8 and h > 8 and c in (0, 1)
+
+    # inference_tiled.py on a larger image, tile = training size
+    big_dir, big_out = os.path.join(tmp, 'big'), os.path.join(tmp, 'bigdets')
+    os.makedirs(big_dir)
+    Image.fromarray(rng.integers(0, 256, (500, 700, 3), dtype=np.uint8)).save(os.path.join(big_dir, 'b.png'))
+    r = subprocess.run([sys.executable, os.path.join(PKG, 'inference_tiled.py'), '--saved-model-filepath', os.path.join(out, 'saved_model'),
+                        '--output-folder', big_out, '--image-folder', big_dir, '--image-format', 'png', '--tile-height', '256',
+                        '--tile-width', '256', '--min-box-size', '8'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = open(os.path.join(big_out, 'b.csv')).read().splitlines()
+    assert lines[0] == 'X,Y,W,H,P,C'
+    for ln in lines[1:]:
+        x, y, w, h, p, c = ln.split(',')
+        assert 0 <= int(x) < 700 and 0 <= int(y) < 500 and 0.1 <= float(p) <= 1.0
+
+
+def test_weight_file_roundtrip(tmp_path):
+    """save_weights / from_file reproduce the model bit for bit (the replacement of the TF checkpoint / SavedModel)."""
+    from yolo3.model import YoloV3
+    a = YoloV3(2, [64, 64, 3], 2, [(64, 384), (384, 64)], seed=3)
+    p = str(tmp_path / 'w.npz')
+    a.save_weights(p)
+    b = YoloV3.from_file(p)
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    assert torch.equal(a.predict(x), b.predict(x))
+    assert b.anchors == a.anchors and b.img_size == a.img_size and b.number_classes == 2
