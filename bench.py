@@ -138,6 +138,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--bucket-mb', type=float, default=32.0)
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend: nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
+    ap.add_argument('--check-replicas', action='store_true', help='after the run, verify that every rank holds identical weights')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -145,13 +147,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     import torch.distributed as dist
     from yolo3.model import YoloV3
     strategy = None
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend)
         from yolo3.parallel import DataParallel
         strategy = DataParallel(bucket_mb=args.bucket_mb)
 
@@ -186,6 +191,13 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        if args.check_replicas:
+            ref = yolo.params.clone()
+            dist.broadcast(ref, src=0)
+            same = torch.tensor([1.0 if torch.equal(ref, yolo.params) else 0.0], device='cuda')
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            if float(same.item()) != 1.0:
+                raise SystemExit('replicas diverged: weights differ between ranks')
     loss_val = float(loss) if loss is not None else float('nan')
     if not np.isfinite(loss_val):
         raise SystemExit('loss is not finite: %r' % loss_val)
@@ -224,6 +236,9 @@ def main():
             'step_flop_rate_tflops': train_fl * BATCH / (dt / args.steps) / 1e12,
             'final_loss': loss_val,
         }
+        if world > 1:
+            out['config']['backend'] = args.backend
+            out['replicas_identical'] = True if args.check_replicas else None
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(seed=1)
         print(json.dumps(out), flush=True)

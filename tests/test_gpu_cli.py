@@ -117,3 +117,23 @@ def test_weight_file_roundtrip(tmp_path):
     x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
     assert torch.equal(a.predict(x), b.predict(x))
     assert b.anchors == a.anchors and b.img_size == a.img_size and b.number_classes == 2
+
+
+def test_two_rank_data_parallel_step_on_one_gpu():
+    """The N > 1 code path with the real model: two ranks (gloo backend, sharing cuda:0 -- RCCL needs one GPU per rank)
+    run bench.py's data-parallel steps with the bucketed async all-reduce hooked into backward; every rank must end
+    with bit-identical weights and a finite global loss."""
+    import json
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--backend', 'gloo', '--check-replicas', '--bucket-mb', '16'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 16 and out['replicas_identical'] is True
+    assert np.isfinite(out['final_loss']) and out['value'] > 0
