@@ -232,7 +232,10 @@ class ImageReader:
                         break
                 return self.keys[label_idx][random.randint(0, len(self.keys[label_idx]) - 1)]
             return self.keys_flat[random.randint(0, len(self.keys_flat) - 1)]
-        fn = self.keys_flat[state['idx']]                     # no shuffle: stride the flat key list by worker id (Q17)
+        # no shuffle: stride the flat key list by worker id (Q17).  The reference indexes keys_flat[worker id] unguarded and
+        # raises IndexError when a database has fewer images than reader processes; wrap instead.
+        state['idx'] %= len(self.keys_flat)
+        fn = self.keys_flat[state['idx']]
         state['idx'] = (state['idx'] + self.nb_workers) % len(self.keys_flat)
         return fn
 
