@@ -278,7 +278,7 @@ struct FastArgs {
     int tap_off[9];   // byte offset of tap t from the pixel base (biased, >= 0)
     int tap_wrow[9];  // weight row of tap t, channel 0
     int tap_dh[9], tap_dw[9];
-    unsigned src_bytes, wt_bytes;
+    unsigned src_bytes, wt_bytes, dst_bytes, resid_bytes;  // extents for the buffer descriptors
     int ntaps;
     int H, W, logC, cmask, src_ld;
     int OH, OW, sh, sw;
@@ -295,7 +295,7 @@ struct FastArgs {
 #define Y3_OOB 0x80000000u
 
 template <int BM, int BN, int WM, int WN, int BK, bool DENSE>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_fast_kernel(const FastArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_kernel(const FastArgs p) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int LDA = BK + 4;
     constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
@@ -441,38 +441,74 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_fast_kernel(const Fas
     float ssum[NB], ssq[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) ssum[j] = ssq[j] = 0.f;
+    if constexpr (DENSE) {
+        // dense destination (pixel index == m): buffer stores with the row part of the offset in the scalar operand and
+        // tile-edge lanes pointed out of range -- no per-element 64-bit address math, no divergent branches.  All 676
+        // workgroups of a layer reach their epilogue together, so its instruction count is exposed, not hidden.
+        const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid ? p.resid : p.dst), 0,
+                                                                               p.resid ? p.resid_bytes : 0u, 0x00020000);
+        const int mrow = m0 + wm * TM + 4 * lh;
+        const unsigned ld4 = (unsigned)p.dst_ld * 4u, rld4 = (unsigned)p.resid_ld * 4u;
+        const bool full = m0 + BM <= p.M;  // wave-uniform: only the last row tile needs per-row masking
+        const bool has_scale = p.scale != nullptr, has_resid = p.resid != nullptr;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int n = n0 + wn * TN + j * 32 + l31;
-        const bool nok = n < p.Nout;
-        const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
-        const float sc = (p.scale && nok) ? p.scale[n] : 1.f;
-        const float sf = (p.scale && nok) ? p.shift[n] : 0.f;
+        for (int j = 0; j < NB; ++j) {
+            const int n = n0 + wn * TN + j * 32 + l31;
+            const bool nok = n < p.Nout;
+            const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+            const float sc = (has_scale && nok) ? p.scale[n] : 1.f;
+            const float sf = (has_scale && nok) ? p.shift[n] : 0.f;
+            const unsigned vbase = nok ? (unsigned)mrow * ld4 + (unsigned)n * 4u : Y3_OOB;
+            const unsigned rbase = nok ? (unsigned)mrow * rld4 + (unsigned)n * 4u : Y3_OOB;
 #pragma unroll
-        for (int i = 0; i < MB; ++i) {
+            for (int i = 0; i < MB; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < p.M && nok) {
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool ok = full ? nok : (nok && mrow + dr < p.M);
+                    const unsigned vo = ok ? vbase : Y3_OOB;
                     float v = acc[i][j][r] + bias;
                     if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
-                    ssum[j] += v;
-                    ssq[j] += v * v;
-                    long long pix;
-                    if (DENSE) {
-                        pix = m;
-                    } else {
+                    const float vs = ok ? v : 0.f;
+                    ssum[j] += vs;
+                    ssq[j] += vs * vs;
+                    if (has_scale) v = v * sc + sf;
+                    if (has_resid) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, ok ? rbase : Y3_OOB, (unsigned)dr * rld4, 0));
+                    if (do_accum) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_dst, vo, (unsigned)dr * ld4, 0));
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_dst, vo, (unsigned)dr * ld4, 0);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int n = n0 + wn * TN + j * 32 + l31;
+            const bool nok = n < p.Nout;
+            const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+            const float sc = (p.scale && nok) ? p.scale[n] : 1.f;
+            const float sf = (p.scale && nok) ? p.shift[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < p.M && nok) {
+                        float v = acc[i][j][r] + bias;
+                        if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
+                        ssum[j] += v;
+                        ssq[j] += v * v;
                         const int nimg = m / ohw;
                         const int rr = m - nimg * ohw;
                         const int oh = rr / p.OW;
                         const int ow = rr - oh * p.OW;
-                        pix = ((long long)nimg * p.DH + oh * p.dsh + p.doh) * p.DW + ow * p.dsw + p.dow;
+                        const long long pix = ((long long)nimg * p.DH + oh * p.dsh + p.doh) * p.DW + ow * p.dsw + p.dow;
+                        if (p.scale) v = v * sc + sf;
+                        if (p.resid) v += p.resid[pix * p.resid_ld + n];
+                        float* d = p.dst + pix * p.dst_ld + n;
+                        if (do_accum) v += *d;
+                        *d = v;
                     }
-                    if (p.scale) v = v * sc + sf;
-                    if (p.resid) v += p.resid[pix * p.resid_ld + n];
-                    float* d = p.dst + pix * p.dst_ld + n;
-                    if (do_accum) v += *d;
-                    *d = v;
                 }
             }
         }
@@ -918,6 +954,13 @@ static bool make_fast(const ConvArgs& a, int ntaps, int bk, FastArgs* f) {
         p.tap_wrow[t] = (int)((a.tap_wsel >> (4 * t)) & 15ull) * a.C;
     }
     p.ntaps = ntaps;
+    {
+        const long long dpix = a.dense_dst ? (long long)a.M : (long long)a.src_n * a.DH * a.DW;
+        const long long db = dpix * a.dst_ld * 4, rb = dpix * (long long)a.resid_ld * 4;
+        if (db >= 0x7fffffffLL || rb >= 0x7fffffffLL) return false;
+        p.dst_bytes = (unsigned)db;
+        p.resid_bytes = (unsigned)rb;
+    }
     p.dst = a.dst;
     p.bias = a.bias;
     p.scale = a.scale;
