@@ -209,6 +209,14 @@ def main():
     conv_s2, per = timed_conv_pass(yolo, plan)        # second pass: caches / clocks settled
     conv_s = min(conv_s, conv_s2)
     achieved = train_fl * BATCH / conv_s / 1e12
+    # HBM-side traffic of the same kernel family comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950,
+    # WRITE_SIZE; see profiles/README.md): bench.py cannot run the profiler on itself, so it reports the committed figure
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as fh:
+            traffic = json.load(fh).get('conv_family_hbm_bytes_per_step')
+    except (OSError, ValueError):
+        pass
 
     if rank == 0:
         out = {
@@ -229,7 +237,7 @@ def main():
                        'global_batch': global_batch, 'per_gpu_batch': BATCH, 'image': [IMG, IMG, 3],
                        'launch': 'hip-graph' if use_graph else 'eager', 'parallelism': 'dp%d' % world},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
                          'kernel': 'conv_igemm_kernel + conv_wgrad_kernel (MFMA implicit-GEMM conv fwd/dgrad/wgrad), %d launches/step' % sum(v[1] for v in per.values()),
                          'flops_per_step': train_fl * BATCH, 'kernel_ms_per_step': conv_s * 1e3,
                          'by_entry_ms': {k: round(v[0] * 1e3, 3) for k, v in per.items()}},

@@ -622,7 +622,7 @@ struct WgradArgs {
     int OH, OW, sh, sw;
     int dd_ld, Nout, K, M;
     int chunk;  // pixels per split (multiple of BP)
-    int nbn;
+    int nbn, tiles, splits;
 };
 
 template <int BKR, int BN, int WM, int WN, int BP>
@@ -642,10 +642,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(const WgradArg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int bid = y3_xcd_remap(blockIdx.x, gridDim.x);
+    // 1-D grid of (splits rounded up to 8) x tiles workgroups.  Blocks are dealt round-robin over the 8 XCDs, so block
+    // L lands on XCD L % 8: give every XCD whole pixel chunks (split = 8 * group + xcd) and let it walk all the
+    // (k-tile, n-tile) pairs of that chunk, so the chunk's activations / gradients are fetched into ONE L2 instead of eight.
+    // (With few chunks that idles XCDs or loses to the tile-major order, measured: then tiles are spread with the usual remap instead.)
+    int split, bid;
+    if (p.splits >= 32) {
+        const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+        split = (jx / p.tiles) * 8 + xcd;
+        bid = jx % p.tiles;
+    } else {
+        split = blockIdx.x / p.tiles;
+        bid = y3_xcd_remap(blockIdx.x % p.tiles, p.tiles);
+    }
+    if (split >= p.splits) return;
     const int bk = bid / p.nbn, bn = bid % p.nbn;
     const int k0 = bk * BKR, n0 = bn * BN;
-    const int mbeg = blockIdx.y * p.chunk;
+    const int mbeg = split * p.chunk;
     const int mend = min(p.M, mbeg + p.chunk);
 
     // A: this thread always loads the same 4 k's (tap, c..c+3); only the pixel advances
@@ -760,7 +773,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(const WgradArg
         cur ^= 1;
     }
 
-    float* out = p.out + (long long)blockIdx.y * p.K * p.Nout;
+    float* out = p.out + (long long)split * p.K * p.Nout;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int n = n0 + wn * TN + j * 32 + l31;
@@ -1298,7 +1311,9 @@ extern "C" int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int 
     Y3_CHECK_ARG(workspace_bytes >= need && (need == 0 || workspace), "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
     p.out = w.splits > 1 ? (float*)workspace : dw;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(w.tiles, w.splits);
+    p.tiles = w.tiles;
+    p.splits = w.splits;
+    dim3 grid((unsigned)((w.splits >= 32 ? y3_cdiv(w.splits, 8) * 8 : w.splits) * w.tiles));
     if (w.bkr == 128 && w.bn == 128)
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 16>), grid, dim3(256), 0, st, p);
     else if (w.bkr == 128 && w.bn == 64)

@@ -6,20 +6,21 @@ import torch
 from yolo3 import _hip
 st = torch.cuda.current_stream().cuda_stream
 n, h, w, cout = 8, 104, 104, 128
-for mode in ('fwd+stats', 'plain'):
-    for cin in (16, 64, 256, 576, 1024):
+import itertools
+for mode, (k, cins) in itertools.product(('fwd+stats', 'plain'), ((1, (16, 64, 256, 576, 1024)), (3, (16, 32, 64, 128)))):
+    for cin in cins:
         x = torch.randn(n * h * w * cin, device='cuda')
         y = torch.empty(n * h * w * cout, device='cuda')
-        wt = torch.randn(cin * cout, device='cuda') * 0.05
+        wt = torch.randn(k * k * cin * cout, device='cuda') * 0.05
         b = torch.zeros(cout, device='cuda')
         stats = torch.empty(n * h * w // 16 * cout + 8192, device='cuda')
         ws = torch.empty(64 << 20, device='cuda')
         X = _hip.Tensor(x.data_ptr(), n, h, w, cin, cin)
         Y = _hip.Tensor(y.data_ptr(), n, h, w, cout, cout)
         if mode == 'plain':
-            run = lambda: _hip.lib.y3_conv2d_fwd(X, wt.data_ptr(), None, 1, 1, Y, 0, 0.0, None, None, None, None, ws.data_ptr(), ws.numel() * 4, st)
+            run = lambda: _hip.lib.y3_conv2d_fwd(X, wt.data_ptr(), None, k, 1, Y, 0, 0.0, None, None, None, None, ws.data_ptr(), ws.numel() * 4, st)
         else:
-            run = lambda: _hip.lib.y3_conv2d_fwd(X, wt.data_ptr(), b.data_ptr(), 1, 1, Y, 1, 0.2, None, None, None, stats.data_ptr(), ws.data_ptr(), ws.numel() * 4, st)
+            run = lambda: _hip.lib.y3_conv2d_fwd(X, wt.data_ptr(), b.data_ptr(), k, 1, Y, 1, 0.2, None, None, None, stats.data_ptr(), ws.data_ptr(), ws.numel() * 4, st)
         assert run() == 0, _hip.lib.y3_last_error()
         torch.cuda.synchronize()
         a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,4 +30,4 @@ for mode in ('fwd+stats', 'plain'):
         e.record()
         torch.cuda.synchronize()
         t = a.elapsed_time(e) / 10 * 1e3
-        print('%-9s K=%4d: %7.1f us   (%.1f TF)' % (mode, cin, t, 2.0 * n * h * w * cin * cout / t / 1e6), flush=True)
+        print('%-9s k=%d K=%4d: %7.1f us   (%.1f TF)' % (mode, k, k * k * cin, t, 2.0 * n * h * w * k * k * cin * cout / t / 1e6), flush=True)
