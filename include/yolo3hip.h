@@ -91,6 +91,11 @@ size_t y3_conv2d_wgrad_workspace(const y3_tensor* src, const y3_tensor* ddst, in
 
 /* wt_t[tap][co][ci] = wt[tap][ci][co] */
 int y3_transpose_weights(const float* wt, float* wt_t, int taps, int cin, int cout, y3_stream_t stream);
+/* The same for every layer of a parameter arena in ONE launch.  table_dev: DEVICE int32 [nlayers][5] =
+ * {arena offset (floats), taps, cin, cout, index of the layer's first 32x32 tile}; total_tiles = sum over layers of
+ * taps * ceil(cin/32) * ceil(cout/32). */
+int y3_transpose_weights_batched(const float* params, float* params_t, const int* table_dev, int nlayers,
+                                 int total_tiles, y3_stream_t stream);
 
 /* ---- BatchNormalization(axis=1), eps 1e-3, momentum .99 (model.py:38) ---- */
 /*

@@ -825,6 +825,37 @@ __global__ void transpose_weights_kernel(const float* __restrict__ w, float* __r
     }
 }
 
+// All layers in one launch: table[l] = {arena offset, taps, cin, cout, first tile}; a block finds its layer by bisection.
+__global__ void transpose_weights_batched_kernel(const float* __restrict__ params, float* __restrict__ params_t,
+                                                 const int* __restrict__ table, int nlayers) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = nlayers - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 5 + 4] <= (int)blockIdx.x)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const int off = table[lo * 5], cin = table[lo * 5 + 2], cout = table[lo * 5 + 3];
+    const int local = blockIdx.x - table[lo * 5 + 4];
+    const int tco = (cout + 31) >> 5, tci = (cin + 31) >> 5;
+    const int t = local / (tco * tci), rem = local % (tco * tci);
+    const int ci0 = (rem / tco) * 32, co0 = (rem % tco) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = params + off + (long long)t * cin * cout;
+    float* dst = params_t + off + (long long)t * cin * cout;
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        tile[r][tx] = (ci < cin && co < cout) ? src[(long long)ci * cout + co] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        if (ci < cin && co < cout) dst[(long long)co * cin + ci] = tile[tx][r];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1340,5 +1371,13 @@ extern "C" int y3_transpose_weights(const float* wt, float* wt_t, int taps, int 
     dim3 grid(y3_cdiv(cout, 32), y3_cdiv(cin, 32), taps);
     hipLaunchKernelGGL(transpose_weights_kernel, grid, dim3(256), 0, (hipStream_t)stream, wt, wt_t, cin, cout);
     Y3_CHECK_LAUNCH("transpose_weights");
+    return Y3_OK;
+}
+
+extern "C" int y3_transpose_weights_batched(const float* params, float* params_t, const int* table_dev, int nlayers, int total_tiles,
+                                            y3_stream_t stream) {
+    Y3_CHECK_ARG(params && params_t && table_dev && nlayers > 0 && total_tiles > 0, "transpose_weights_batched: bad args");
+    hipLaunchKernelGGL(transpose_weights_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, params, params_t, table_dev, nlayers);
+    Y3_CHECK_LAUNCH("transpose_weights_batched");
     return Y3_OK;
 }

@@ -470,26 +470,24 @@ extern "C" int y3_nhwc_to_nchw(const y3_tensor* src, float* dst, y3_stream_t str
     return Y3_OK;
 }
 
-// out[c] = sum over pixels; single block, fp64 accumulation, fixed order (deterministic)
+// out[c] = sum over pixels; one block per channel, fp64 accumulation, fixed order (deterministic)
 __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ src, int ld, int C, long long npix, float* __restrict__ out) {
     __shared__ double sm[1024];
-    for (int c = 0; c < C; ++c) {
-        double s = 0.0;
-        for (long long r = threadIdx.x; r < npix; r += 1024) s += (double)src[r * ld + c];
-        sm[threadIdx.x] = s;
-        __syncthreads();
-        for (int o = 512; o > 0; o >>= 1) {
-            if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) out[c] = (float)sm[0];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (long long r = threadIdx.x; r < npix; r += 1024) s += (double)src[r * ld + c];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
         __syncthreads();
     }
+    if (threadIdx.x == 0) out[c] = (float)sm[0];
 }
 extern "C" int y3_colsum(const y3_tensor* src, float* out, y3_stream_t stream) {
     if (int e = check_view(src, "colsum src")) return e;
-    Y3_CHECK_ARG(out && src->c <= 1024, "colsum: meant for the detection heads (c <= 1024)");
-    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, src->ptr, src->ld, src->c, pixels(src), out);
+    Y3_CHECK_ARG(out && src->c <= 65535, "colsum: bad args");
+    hipLaunchKernelGGL(colsum_kernel, dim3(src->c), dim3(1024), 0, (hipStream_t)stream, src->ptr, src->ld, src->c, pixels(src), out);
     Y3_CHECK_LAUNCH("colsum");
     return Y3_OK;
 }

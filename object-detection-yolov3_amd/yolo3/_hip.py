@@ -48,6 +48,7 @@ SIGNATURES = {
     'y3_conv2d_wgrad': (i32, [TP, TP, i32, i32, fp, vp, sz, vp]),
     'y3_conv2d_wgrad_workspace': (sz, [TP, TP, i32, i32]),
     'y3_transpose_weights': (i32, [fp, fp, i32, i32, i32, vp]),
+    'y3_transpose_weights_batched': (i32, [fp, fp, ip, i32, i32, vp]),
     'y3_bn_stats_finalize': (i32, [fp, i32, i32, i32, fp, fp, f32, f32, fp, fp, fp, fp, fp, fp, vp]),
     'y3_bn_fold_inference': (i32, [fp, fp, fp, fp, f32, i32, fp, fp, vp]),
     'y3_bn_apply': (i32, [TP, fp, fp, TP, TP, vp]),

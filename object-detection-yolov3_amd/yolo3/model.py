@@ -524,6 +524,7 @@ class YoloV3:
         self.use_graph = bool(use_graph)
         self.dist = None                          # set by parallel.DataParallel.attach()
         self._plans = {}
+        self._tr_table = None
         self._init_weights(seed)
         self.model = _CallableModel(self, False)
         self.model_feature_maps = _CallableModel(self, True)
@@ -640,10 +641,16 @@ class YoloV3:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def _refresh_transposed(self):
-        st = self._stream()
-        for sp in self.specs[1:]:
-            check(lib.y3_transpose_weights(self.params.data_ptr() + 4 * sp.w_off, self.params_t.data_ptr() + 4 * sp.w_off, sp.k * sp.k,
-                                           sp.cin_pad, sp.cout, st), 'y3_transpose_weights')
+        """params_t <- kernels with the channel axes swapped (operand of the data gradient), all layers in one launch."""
+        if self._tr_table is None:
+            rows, start = [], 0
+            for sp in self.specs[1:]:          # the first layer has no data gradient
+                rows.append([sp.w_off, sp.k * sp.k, sp.cin_pad, sp.cout, start])
+                start += sp.k * sp.k * (-(-sp.cin_pad // 32)) * (-(-sp.cout // 32))
+            self._tr_table = torch.tensor(rows, dtype=torch.int32, device=self.device)
+            self._tr_tiles = start
+        check(lib.y3_transpose_weights_batched(self.params.data_ptr(), self.params_t.data_ptr(), self._tr_table.data_ptr(), len(self.specs) - 1,
+                                               self._tr_tiles, self._stream()), 'y3_transpose_weights_batched')
 
     # ---- reference API (model.py:466-479) ---------------------------------------------
     def get_keras_model(self):
