@@ -137,6 +137,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-inference', action='store_true', help='skip the secondary inference measurement (config: bs=8 fp32 predict + NMS)')
     ap.add_argument('--bucket-mb', type=float, default=32.0)
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument('--check-replicas', action='store_true', help='after the run, verify that every rank holds identical weights')
@@ -218,6 +219,30 @@ def main():
     except (OSError, ValueError):
         pass
 
+    # secondary (BASELINE.json configs[1]): inference bs=8 416x416 fp32 -- z-scored batch -> conv stacks with folded BN ->
+    # decode -> clip + small-box filter + class-wise NMS, all on the GPU; reported beside the headline metric
+    infer = None
+    if world == 1 and not args.no_inference:
+        from yolo3 import bbox_utils
+        for _ in range(3):
+            rows = yolo.predict(images)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_inf = 10
+        for _ in range(n_inf):
+            rows = yolo.predict(images)
+        torch.cuda.synchronize()
+        t_fwd = (time.perf_counter() - t1) / n_inf
+        bbox_utils.nms_device(rows, 32.0, clip_wh=(IMG, IMG))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_inf):
+            bbox_utils.nms_device(rows, 32.0, clip_wh=(IMG, IMG))
+        torch.cuda.synchronize()
+        t_nms = (time.perf_counter() - t1) / n_inf
+        infer = {'images_per_s_forward_decode': BATCH / t_fwd, 'ms_forward_decode': t_fwd * 1e3, 'ms_nms_batch8': t_nms * 1e3,
+                 'forward_tflops': fwd_fl * BATCH / t_fwd / 1e12, 'forward_frac_of_fp32_mfma_peak': fwd_fl * BATCH / t_fwd / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+
     if rank == 0:
         out = {
             'metric': 'images/sec (train fwd+bwd) bs=8 416x416',
@@ -244,6 +269,8 @@ def main():
             'step_flop_rate_tflops': train_fl * BATCH / (dt / args.steps) / 1e12,
             'final_loss': loss_val,
         }
+        if infer is not None:
+            out['inference_bs8_fp32'] = infer
         if world > 1:
             out['config']['backend'] = args.backend
             out['replicas_identical'] = True if args.check_replicas else None

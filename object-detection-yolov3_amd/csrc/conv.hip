@@ -481,34 +481,49 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_kernel(const 
             }
         }
     } else {
+        // strided destination (the four parity launches of a stride-2 data gradient): decompose each accumulator row
+        // once (not once per column block), then the same buffer-store epilogue as above
+        const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid ? p.resid : p.dst), 0,
+                                                                               p.resid ? p.resid_bytes : 0u, 0x00020000);
+        const bool has_scale = p.scale != nullptr, has_resid = p.resid != nullptr;
+        unsigned rowpix[MB][16];
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int mm = m < p.M ? m : 0;
+                const int nimg = mm / ohw;
+                const int rr = mm - nimg * ohw;
+                const int oh = rr / p.OW;
+                const int ow = rr - oh * p.OW;
+                const unsigned pix = (unsigned)((nimg * p.DH + oh * p.dsh + p.doh) * p.DW + ow * p.dsw + p.dow);
+                rowpix[i][r] = m < p.M ? pix : 0xffffffffu;
+            }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int n = n0 + wn * TN + j * 32 + l31;
             const bool nok = n < p.Nout;
             const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
-            const float sc = (p.scale && nok) ? p.scale[n] : 1.f;
-            const float sf = (p.scale && nok) ? p.shift[n] : 0.f;
+            const float sc = (has_scale && nok) ? p.scale[n] : 1.f;
+            const float sf = (has_scale && nok) ? p.shift[n] : 0.f;
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < p.M && nok) {
-                        float v = acc[i][j][r] + bias;
-                        if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
-                        ssum[j] += v;
-                        ssq[j] += v * v;
-                        const int nimg = m / ohw;
-                        const int rr = m - nimg * ohw;
-                        const int oh = rr / p.OW;
-                        const int ow = rr - oh * p.OW;
-                        const long long pix = ((long long)nimg * p.DH + oh * p.dsh + p.doh) * p.DW + ow * p.dsw + p.dow;
-                        if (p.scale) v = v * sc + sf;
-                        if (p.resid) v += p.resid[pix * p.resid_ld + n];
-                        float* d = p.dst + pix * p.dst_ld + n;
-                        if (do_accum) v += *d;
-                        *d = v;
-                    }
+                    const bool ok = nok && rowpix[i][r] != 0xffffffffu;
+                    const unsigned vo = ok ? (rowpix[i][r] * (unsigned)p.dst_ld + (unsigned)n) * 4u : Y3_OOB;
+                    float v = acc[i][j][r] + bias;
+                    if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
+                    const float vs = ok ? v : 0.f;
+                    ssum[j] += vs;
+                    ssq[j] += vs * vs;
+                    if (has_scale) v = v * sc + sf;
+                    if (has_resid)
+                        v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, ok ? (rowpix[i][r] * (unsigned)p.resid_ld + (unsigned)n) * 4u : Y3_OOB, 0, 0));
+                    if (do_accum) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_dst, vo, 0, 0));
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_dst, vo, 0, 0);
                 }
             }
         }
@@ -926,7 +941,10 @@ static ConvPlan plan_conv(int M, int Nout, int K, bool fast_ok) {
     const long long tiles = (long long)y3_cdiv(M, pl.t.bm) * y3_cdiv(Nout, pl.t.bn);
     static const int want = env_int("Y3_SPLITK_WGS", 1400);   // workgroups to aim for
     static const int min_k = env_int("Y3_SPLITK_MINK", 256);  // shortest K slice worth a launch
-    if (fast_ok && Nout <= 1024 && tiles * 2 <= want && K >= 2 * min_k) {
+    // measured (tools/fixed_cost.py, layer_times.py): a 676-tile launch (2.6 workgroups per CU) is better left whole unless
+    // K is long; at <= 512 tiles the extra workgroups win over the slab round trip
+    const bool few_tiles = tiles <= 512 || (tiles * 2 <= want && K >= 2048);
+    if (fast_ok && Nout <= 1024 && few_tiles && K >= 2 * min_k) {
         int ks = (int)((want + tiles / 2) / tiles);
         const int maxs = K / min_k;
         if (ks > maxs) ks = maxs;
