@@ -156,3 +156,55 @@ def test_test_step_and_graph_replay():
     np.testing.assert_allclose(la, lb, rtol=1e-5)
     for wa, wb in zip(a.trainable_weights(), b.trainable_weights()):
         np.testing.assert_allclose(wa, wb, rtol=0, atol=2.1e-3)
+
+
+def test_nonsquare_grayscale_three_anchors():
+    """Edge cases of the contract: 1-channel input (padded 1 -> 4 internally), non-square image (the Q6 stride quirk:
+    x uses H//G_h, y uses W//G_w), the default three anchors and three classes (24 head channels), odd grid sizes.
+    Inference and one training step against the oracle."""
+    from oracle import model as om
+    from yolo3.model import YoloV3
+    from yolo3.imagereader import format_boxes
+    anchors, K3, H, W, n = [(32, 32), (128, 128), (256, 256)], 3, 96, 160, 2
+    params = om.init_params(1, 3, K3, seed=21, randomize_bn=True)
+    for p in params:
+        if 'gamma' not in p:
+            p['W'] *= 0.02
+    g = torch.Generator().manual_seed(21)
+    images = torch.randn(n, 1, H, W, generator=g)
+    yolo = YoloV3(n, [H, W, 1], K3)             # anchors=None -> the reference default (model.py:433)
+    assert yolo.anchors == anchors
+    yolo.set_weights(params)
+    out = yolo.predict(images.cuda()).cpu().numpy()
+    refs = {}
+    for dt in (torch.float32, torch.float64):
+        net = om.Net(params, 1, 3, K3, dtype=dt)
+        with torch.no_grad():
+            refs[dt] = om.decode(net.feature_maps(images.to(dt), training=False), (H, W, 1), anchors, K3).numpy()
+    assert out.shape == (n, 3 * (3 * 5 + 6 * 10 + 12 * 20), 5 + K3)
+    den = np.abs(refs[torch.float64]) + 1.0
+    _check(out / den, refs[torch.float32] / den, refs[torch.float64] / den, 'non-square decode', mult=10.0)
+    # one training step (Keras-default BN so batch statistics matter)
+    params = om.init_params(1, 3, K3, seed=22)
+    yolo.set_weights(params)
+    rng = np.random.default_rng(22)
+    labs = []
+    for _ in range(n):
+        wh = rng.integers(20, 60, (2, 2))
+        xy = np.stack([rng.integers(0, W - wh[:, 0]), rng.integers(0, H - wh[:, 1])], 1)
+        labs.append(format_boxes(np.concatenate([xy, wh, rng.integers(0, K3, (2, 1))], 1).astype(np.int32), (H, W, 1), anchors, K3))
+    gts = [np.stack([l[s] for l in labs]) for s in range(3)]
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        net = om.Net(params, 1, 3, K3, dtype=dt, requires_grad=True)
+        res[dt] = om.train_step(net, om.AdamState(net.trainable(), 1e-3), images.to(dt), [torch.from_numpy(x) for x in gts], (H, W, 1), anchors, K3, n, apply=False)
+    loss = float(yolo.train_step((images.cuda(), [torch.from_numpy(x).cuda() for x in gts])))
+    r32, r64 = res[torch.float32], res[torch.float64]
+    assert abs(loss - r64['loss']) <= 6 * abs(r32['loss'] - r64['loss']) + 1e-5 * abs(r64['loss']), (loss, r64['loss'])
+    flat = []
+    for sp, d in zip(yolo.specs, yolo.get_gradients()):
+        flat += [d['W'], d['b']] + ([d['gamma'], d['beta']] if sp.bn else [])
+    for i, (gg, a, b) in enumerate(zip(flat, r32['grads'], r64['grads'])):
+        a, b, gg = a.numpy().astype(np.float64), b.numpy(), np.asarray(gg, np.float64)
+        nb = np.linalg.norm(b) + 1e-30
+        assert np.isfinite(gg).all() and np.linalg.norm(gg - b) / nb <= 6.0 * np.linalg.norm(a - b) / nb + 5e-3, i
