@@ -113,6 +113,10 @@ int y3_bn_stats_finalize(const float* stats, int tiles, int c, int count,
 int y3_bn_fold_inference(const float* gamma, const float* beta, const float* moving_mean,
                          const float* moving_var, float eps, int c, float* scale, float* shift,
                          y3_stream_t stream);
+/* The same for every BatchNorm layer in ONE launch.  table_dev: DEVICE int32 [nlayers][7] = float offsets of
+ * {gamma, beta} in `params`, {moving mean, moving var} in `moving`, {scale, shift} in `chan`, and the channel count. */
+int y3_bn_fold_inference_batched(const float* params, const float* moving, float* chan, const int* table_dev,
+                                 int nlayers, float eps, y3_stream_t stream);
 /* y = a*scale + shift (+ resid)   (BN apply and the residual add of model.py:47) */
 int y3_bn_apply(const y3_tensor* a, const float* scale, const float* shift, const y3_tensor* resid,
                 const y3_tensor* y, y3_stream_t stream);
@@ -138,6 +142,20 @@ int y3_bn_bwd_apply(const y3_tensor* dy, const y3_tensor* a, const float* coef, 
 int y3_upsample_sum2x_fwd(const y3_tensor* in, const y3_tensor* out, y3_stream_t stream);
 /* din[n,i,j,ci] = sum_{a,b,co} dout[n,2i+a,2j+b,co] for every ci */
 int y3_upsample_sum2x_bwd(const y3_tensor* dout, const y3_tensor* din, y3_stream_t stream);
+
+/* ---- bf16 inference path (BASELINE config 5: tiled inference with a bf16 conv path) ----------------
+ * Tensors are NHWC with `ld` counted in ELEMENTS; `ptr` addresses bf16 (2-byte) elements unless noted.
+ * Replaces the same Conv2D -> LeakyReLU -> BatchNorm(training=False) chain as y3_conv2d_fwd
+ * (model.py:71-91,108-137) when inference runs in reduced precision: bf16 operands, fp32 accumulate on
+ * v_mfma_f32_32x32x16_bf16, fp32 epilogue (bias, lrelu, folded BN scale/shift, residual), one rounding on store.
+ * wt_t_bf16 is the y3_transpose_weights layout [kh][kw][Cout][Cin] converted with y3_f32_to_bf16.
+ * Requires Cin % 32 == 0 (the first RGB layer stays on y3_conv2d_fwd).  dst_is_f32 != 0 writes fp32
+ * (used for the three head convs so that decode / NMS stay fp32). */
+int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, const float* bias, int ksize, int stride,
+                       const y3_tensor* dst, int dst_is_f32, unsigned flags, float alpha,
+                       const float* scale, const float* shift, const y3_tensor* resid, y3_stream_t stream);
+int y3_f32_to_bf16(const float* src, void* dst, size_t count, y3_stream_t stream); /* round-to-nearest-even */
+int y3_upsample_sum2x_fwd_bf16(const y3_tensor* in, const y3_tensor* out, y3_stream_t stream); /* model.py:94-105 */
 
 /* ---- small data movement -------------------------------------------------- */
 int y3_copy(const y3_tensor* src, const y3_tensor* dst, y3_stream_t stream);        /* strided copy (tf.concat, model.py:368,375) */

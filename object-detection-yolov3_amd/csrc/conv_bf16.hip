@@ -1,0 +1,348 @@
+// bf16 inference convolution (BASELINE config 5: tiled inference, "bf16 conv path + fp32 NMS").
+//
+// Same gather-GEMM as conv.hip's fast path, with bf16 operands and fp32 accumulation on
+// v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate):
+//   A: activations NHWC bf16 (K = (tap, c) contiguous per pixel)
+//   B: kernels in the [tap][Cout][Cin] layout of the transposed-weight arena, converted to bf16 -- K-contiguous per
+//      output channel, so BOTH operands are "rows of 32 bf16 = 64 bytes" and share one loader and one LDS image:
+//      rows padded to 80 bytes, fragment = one conflict-free ds_read_b128 (8 bf16) at quad 2*kk + (lane >> 5).
+// Epilogue: + bias -> leaky-relu -> folded BatchNorm affine -> + residual (bf16) -> bf16 (or fp32 for the heads).
+// At 64 bytes of operands per 32 MFMA cycles this kernel is bound by the L2 -> LDS path, not by the matrix pipe.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+struct Bf16Args {
+    const u16* src;  // biased so every tap offset is >= 0
+    const u16* wt;
+    void* dst;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    const u16* resid;
+    int tap_off[9];  // bytes
+    int tap_wt[9];   // element offset of tap t in wt (t * Cout * Cin)
+    int tap_dh[9], tap_dw[9];
+    unsigned src_bytes, wt_bytes, dst_bytes, resid_bytes;
+    int ntaps;
+    int H, W, C, logC, cmask, src_ld;
+    int OH, OW, sh, sw;
+    int dst_ld, resid_ld;
+    int Nout, K, M;
+    unsigned flags;
+    float alpha;
+    int nbn, out_f32;
+};
+
+#define Y3_OOB 0x80000000u
+
+__device__ __forceinline__ float bf16_to_f32(u16 v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ u16 f32_to_bf16(float f) {  // round to nearest even; NaN stays NaN
+    return __builtin_bit_cast(u16, (__bf16)f);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args p) {
+    constexpr int THREADS = 64 * WM * WN;
+    constexpr int BK = 32;                // bf16 per K step = 64 bytes per row
+    constexpr int LDR = 40;               // row pitch in u16 (80 bytes: conflict-free 16-byte fragment reads)
+    constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
+    constexpr int A_LOADS = BM * 4 / THREADS, B_LOADS = (BN * 4 + THREADS - 1) / THREADS;
+    static_assert(BM * 4 % THREADS == 0 && TM % 32 == 0 && TN % 32 == 0, "tile shape");
+
+    __shared__ __attribute__((aligned(16))) u16 As[2][BM * LDR];
+    __shared__ __attribute__((aligned(16))) u16 Bs[2][BN * LDR];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int bid = y3_xcd_remap(blockIdx.x, gridDim.x);
+    const int bm = bid / p.nbn, bn = bid % p.nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int ohw = p.OH * p.OW;
+
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.wt), 0, p.wt_bytes, 0x00020000);
+
+    unsigned a_voff[A_LOADS], a_mask[A_LOADS];
+    const int quad = tid & 3;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int row = (tid + i * THREADS) >> 2;
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / ohw;
+        const int r = mm - n * ohw;
+        const int oh = r / p.OW;
+        const int ow = r - oh * p.OW;
+        const int ih0 = oh * p.sh, iw0 = ow * p.sw;
+        a_voff[i] = (unsigned)(((n * p.H + ih0) * p.W + iw0) * p.src_ld + quad * 8) * 2u;
+        unsigned msk = 0;
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int ih = ih0 + p.tap_dh[t], iw = iw0 + p.tap_dw[t];
+            if (ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) msk |= 1u << t;
+        }
+        a_mask[i] = msk;
+    }
+    unsigned b_voff[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int idx = tid + i * THREADS;
+        const int n = n0 + (idx >> 2);
+        b_voff[i] = (idx < BN * 4 && n < p.Nout) ? (unsigned)(n * p.C + quad * 8) * 2u : Y3_OOB;
+    }
+
+    f32x4 ra[A_LOADS], rb[B_LOADS];
+    auto gload = [&](int k0) {
+        const int tap = k0 >> p.logC;
+        const int cb = k0 & p.cmask;
+        const unsigned a_soff = (unsigned)(p.tap_off[tap] + cb * 2);
+        const unsigned b_soff = (unsigned)(p.tap_wt[tap] + cb) * 2u;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i)
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, ((a_mask[i] >> tap) & 1u) ? a_voff[i] : Y3_OOB, a_soff, 0);
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[i], b_soff, 0);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) *reinterpret_cast<f32x4*>(&As[buf][((tid + i * THREADS) >> 2) * LDR + quad * 8]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int idx = tid + i * THREADS;
+            if (BN * 4 % THREADS == 0 || idx < BN * 4) *reinterpret_cast<f32x4*>(&Bs[buf][(idx >> 2) * LDR + quad * 8]) = rb[i];
+        }
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        const bool more = ks + 1 < nk;
+        if (more) gload((ks + 1) * BK);
+        const u16* as = &As[cur][(wm * TM + l31) * LDR + lh * 8];
+        const u16* bs = &Bs[cur][(wn * TN + l31) * LDR + lh * 8];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 av[MB], bv[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) av[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * LDR + kk * 16);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * LDR + kk * 16);
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: D layout col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const bool do_lrelu = p.flags & Y3_EPI_LRELU;
+    const bool has_scale = p.scale != nullptr, has_resid = p.resid != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.resid ? p.resid : p.src), 0,
+                                                                           p.resid ? p.resid_bytes : 0u, 0x00020000);
+    const int mrow = m0 + wm * TM + 4 * lh;
+    const unsigned esz = p.out_f32 ? 4u : 2u;
+    const unsigned ldb = (unsigned)p.dst_ld * esz, rldb = (unsigned)p.resid_ld * 2u;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * TN + j * 32 + l31;
+        const bool nok = n < p.Nout;
+        const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+        const float sc = (has_scale && nok) ? p.scale[n] : 1.f;
+        const float sf = (has_scale && nok) ? p.shift[n] : 0.f;
+        const unsigned vbase = (unsigned)mrow * ldb + (unsigned)n * esz;
+        const unsigned rbase = (unsigned)mrow * rldb + (unsigned)n * 2u;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+                const bool ok = nok && mrow + dr < p.M;
+                float v = acc[i][j][r] + bias;
+                if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
+                if (has_scale) v = v * sc + sf;
+                if (has_resid) v += bf16_to_f32((u16)__builtin_amdgcn_raw_buffer_load_b16(rs_res, ok ? rbase : Y3_OOB, (unsigned)dr * rldb, 0));
+                if (p.out_f32)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_dst, ok ? vbase : Y3_OOB, (unsigned)dr * ldb, 0);
+                else
+                    __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(v), rs_dst, ok ? vbase : Y3_OOB, (unsigned)dr * ldb, 0);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// small bf16 helpers
+// ---------------------------------------------------------------------------
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[i] = f32_to_bf16(src[i]);
+}
+
+// all-ones transposed conv (model.py:94-105) on bf16: one wave per input pixel, fp32 sum over channels
+__global__ __launch_bounds__(256) void upsample_bf16_kernel(const u16* __restrict__ in, int in_ld, int C, u16* __restrict__ out, int out_ld,
+                                                            int outC, int N, int H, int W) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long npix = (long long)N * H * W;
+    if (wave >= npix) return;
+    const u16* src = in + wave * in_ld;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += bf16_to_f32(src[c]);
+    s = y3_wave_sum(s);
+    const u16 o = f32_to_bf16(s);
+    const int n = (int)(wave / ((long long)H * W));
+    const int r = (int)(wave - (long long)n * H * W);
+    const int i = r / W, j = r - i * W;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            u16* dst = out + (((long long)n * 2 * H + 2 * i + a) * 2 * W + 2 * j + b) * out_ld;
+            for (int c = lane; c < outC; c += 64) dst[c] = o;
+        }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static int check_bf16_tensor(const y3_tensor* t, const char* name) {
+    Y3_CHECK_ARG(t && t->ptr, "%s: null tensor", name);
+    Y3_CHECK_ARG(t->n > 0 && t->h > 0 && t->w > 0 && t->c > 0 && t->ld >= t->c, "%s: bad dims", name);
+    return 0;
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_bf16(const Bf16Args& p, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, WM, WN>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
+}
+
+extern "C" int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, const float* bias, int ksize, int stride, const y3_tensor* dst,
+                                  int dst_is_f32, unsigned flags, float alpha, const float* scale, const float* shift, const y3_tensor* resid,
+                                  y3_stream_t stream) {
+    if (int e = check_bf16_tensor(src, "conv2d_fwd_bf16 src")) return e;
+    if (int e = check_bf16_tensor(dst, "conv2d_fwd_bf16 dst")) return e;
+    Y3_CHECK_ARG(wt_t_bf16, "conv2d_fwd_bf16: null weights");
+    Y3_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_fwd_bf16: ksize %d unsupported", ksize);
+    Y3_CHECK_ARG(stride == 1 || stride == 2, "conv2d_fwd_bf16: stride %d unsupported", stride);
+    Y3_CHECK_ARG(src->c % 32 == 0 && (src->ld & 7) == 0 && ((uintptr_t)src->ptr & 15) == 0, "conv2d_fwd_bf16: Cin=%d must be a multiple of 32, ld of 8, 16-byte aligned", src->c);
+    Y3_CHECK_ARG(ksize == 1 || y3_is_pow2(src->c), "conv2d_fwd_bf16: 3x3 needs power-of-two channels");
+    const int OH = (src->h + stride - 1) / stride, OW = (src->w + stride - 1) / stride;
+    Y3_CHECK_ARG(dst->n == src->n && dst->h == OH && dst->w == OW, "conv2d_fwd_bf16: dst geometry");
+    Y3_CHECK_ARG((scale == nullptr) == (shift == nullptr), "conv2d_fwd_bf16: scale/shift must both be given");
+    Bf16Args p = {};
+    const int taps = ksize * ksize;
+    const int pbh = y3_same_pad_before(src->h, ksize, stride), pbw = y3_same_pad_before(src->w, ksize, stride);
+    int min_off = 0;
+    for (int kh = 0; kh < ksize; ++kh)
+        for (int kw = 0; kw < ksize; ++kw) {
+            const int t = kh * ksize + kw;
+            p.tap_dh[t] = kh - pbh;
+            p.tap_dw[t] = kw - pbw;
+            const int off = (p.tap_dh[t] * src->w + p.tap_dw[t]) * src->ld;
+            if (off < min_off) min_off = off;
+        }
+    for (int t = 0; t < taps; ++t) {
+        p.tap_off[t] = ((p.tap_dh[t] * src->w + p.tap_dw[t]) * src->ld - min_off) * 2;
+        p.tap_wt[t] = t * dst->c * src->c;
+    }
+    const long long sbytes = ((long long)src->n * src->h * src->w * src->ld - min_off) * 2;
+    const long long wbytes = (long long)taps * dst->c * src->c * 2;
+    const long long M = (long long)src->n * OH * OW;
+    const long long dbytes = M * dst->ld * (dst_is_f32 ? 4 : 2);
+    Y3_CHECK_ARG(sbytes < 0x7fffffffLL && wbytes < 0x7fffffffLL && dbytes < 0x7fffffffLL, "conv2d_fwd_bf16: tensor exceeds 2 GiB (split the batch)");
+    p.src = (const u16*)src->ptr + min_off;
+    p.src_bytes = (unsigned)sbytes;
+    p.wt = (const u16*)wt_t_bf16;
+    p.wt_bytes = (unsigned)wbytes;
+    p.dst = dst->ptr;
+    p.dst_bytes = (unsigned)dbytes;
+    p.bias = bias;
+    p.scale = scale;
+    p.shift = shift;
+    if (resid) {
+        if (int e = check_bf16_tensor(resid, "conv2d_fwd_bf16 resid")) return e;
+        Y3_CHECK_ARG(resid->n == dst->n && resid->h == dst->h && resid->w == dst->w && resid->c == dst->c, "conv2d_fwd_bf16: resid geometry");
+        p.resid = (const u16*)resid->ptr;
+        p.resid_ld = resid->ld;
+        p.resid_bytes = (unsigned)(M * resid->ld * 2);
+    }
+    p.ntaps = taps;
+    p.H = src->h;
+    p.W = src->w;
+    p.C = src->c;
+    if (taps == 1) {
+        p.logC = 31;
+        p.cmask = 0x7fffffff;
+    } else {
+        p.logC = y3_ilog2(src->c);
+        p.cmask = src->c - 1;
+    }
+    p.src_ld = src->ld;
+    p.OH = OH;
+    p.OW = OW;
+    p.sh = p.sw = stride;
+    p.dst_ld = dst->ld;
+    p.Nout = dst->c;
+    p.K = taps * src->c;
+    p.M = (int)M;
+    p.flags = flags;
+    p.alpha = alpha;
+    p.out_f32 = dst_is_f32;
+    hipStream_t st = (hipStream_t)stream;
+    // tiles: the kernel is load bound, so prefer the largest tile that still gives >= ~2 workgroups per CU
+    const long long t128 = (long long)y3_cdiv(p.M, 128) * y3_cdiv(p.Nout, 128);
+    if (p.Nout <= 32) {
+        p.nbn = 1;
+        launch_bf16<128, 32, 4, 1>(p, y3_cdiv(p.M, 128), st);
+    } else if (p.Nout <= 64) {
+        p.nbn = 1;
+        launch_bf16<128, 64, 4, 1>(p, y3_cdiv(p.M, 128), st);
+    } else if (t128 >= 512) {
+        p.nbn = y3_cdiv(p.Nout, 128);
+        launch_bf16<128, 128, 2, 2>(p, y3_cdiv(p.M, 128) * p.nbn, st);
+    } else {
+        p.nbn = y3_cdiv(p.Nout, 64);
+        launch_bf16<64, 64, 2, 2>(p, y3_cdiv(p.M, 64) * p.nbn, st);
+    }
+    Y3_CHECK_LAUNCH("conv_bf16");
+    return Y3_OK;
+}
+
+extern "C" int y3_f32_to_bf16(const float* src, void* dst, size_t count, y3_stream_t stream) {
+    Y3_CHECK_ARG((src && dst) || count == 0, "f32_to_bf16: null pointer");
+    if (count == 0) return Y3_OK;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (u16*)dst, count);
+    Y3_CHECK_LAUNCH("f32_to_bf16");
+    return Y3_OK;
+}
+
+extern "C" int y3_upsample_sum2x_fwd_bf16(const y3_tensor* in, const y3_tensor* out, y3_stream_t stream) {
+    if (int e = check_bf16_tensor(in, "upsample_bf16 in")) return e;
+    if (int e = check_bf16_tensor(out, "upsample_bf16 out")) return e;
+    Y3_CHECK_ARG(out->n == in->n && out->h == 2 * in->h && out->w == 2 * in->w, "upsample_bf16: geometry");
+    const long long npix = (long long)in->n * in->h * in->w;
+    hipLaunchKernelGGL(upsample_bf16_kernel, dim3(y3_cdiv(npix, 4)), dim3(256), 0, (hipStream_t)stream, (const u16*)in->ptr, in->ld, in->c,
+                       (u16*)out->ptr, out->ld, out->c, in->n, in->h, in->w);
+    Y3_CHECK_LAUNCH("upsample_bf16");
+    return Y3_OK;
+}

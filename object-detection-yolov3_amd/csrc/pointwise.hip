@@ -100,6 +100,31 @@ extern "C" int y3_bn_fold_inference(const float* gamma, const float* beta, const
     return Y3_OK;
 }
 
+// every BatchNorm layer of the network in one launch: table rows {gamma, beta, moving mean, moving var, scale, shift (float offsets), C}
+__global__ void bn_fold_batched_kernel(const float* __restrict__ params, const float* __restrict__ moving, float* __restrict__ chan,
+                                       const int* __restrict__ table, float eps) {
+    const int* row = table + blockIdx.x * 7;
+    const float* gamma = params + row[0];
+    const float* beta = params + row[1];
+    const float* mean = moving + row[2];
+    const float* var = moving + row[3];
+    float* scale = chan + row[4];
+    float* shift = chan + row[5];
+    const int C = row[6];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float sc = gamma[c] * (1.f / sqrtf(var[c] + eps));
+        scale[c] = sc;
+        shift[c] = beta[c] - mean[c] * sc;
+    }
+}
+extern "C" int y3_bn_fold_inference_batched(const float* params, const float* moving, float* chan, const int* table_dev, int nlayers, float eps,
+                                            y3_stream_t stream) {
+    Y3_CHECK_ARG(params && moving && chan && table_dev && nlayers > 0, "bn_fold_inference_batched: bad args");
+    hipLaunchKernelGGL(bn_fold_batched_kernel, dim3(nlayers), dim3(256), 0, (hipStream_t)stream, params, moving, chan, table_dev, eps);
+    Y3_CHECK_LAUNCH("bn_fold_inference_batched");
+    return Y3_OK;
+}
+
 // y = a*scale + shift (+ resid)
 __global__ void bn_apply_kernel(const float* __restrict__ a, int a_ld, const float* __restrict__ scale, const float* __restrict__ shift,
                                 const float* __restrict__ resid, int r_ld, float* __restrict__ y, int y_ld, long long npix, int c4) {

@@ -19,12 +19,13 @@ def load_model(path):
     return YoloV3.from_file(path)
 
 
-def inference(image_folder, image_format, saved_model_filepath, output_folder, min_box_size):
+def inference(image_folder, image_format, saved_model_filepath, output_folder, min_box_size, precision='fp32'):
     os.makedirs(output_folder, exist_ok=True)
     if image_format.startswith('.'):
         image_format = image_format[1:]
     img_filepath_list = [os.path.join(image_folder, fn) for fn in os.listdir(image_folder) if fn.endswith('.{}'.format(image_format))]
     yolo = load_model(saved_model_filepath)
+    yolo.inference_precision = precision          # 'bf16': bf16 MFMA convs, fp32 heads / decode / NMS (not in the reference)
     yolo_model = yolo.get_keras_model()
     print('Starting inference of file list')
     for i, img_filepath in enumerate(img_filepath_list):
@@ -56,8 +57,9 @@ if __name__ == '__main__':
     parser.add_argument('--image-folder', dest='image_folder', type=str, required=True)
     parser.add_argument('--image-format', dest='image_format', type=str, default='tif')
     parser.add_argument('--min-box-size', type=int, default=32, help='Smallest detection to consider. Default (32, 32).')
+    parser.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32', help='conv arithmetic (extension; the reference is fp32)')
     a = parser.parse_args()
     print('Arguments:')
     for k, v in vars(a).items():
         print('{} = {}'.format(k, v))
-    inference(a.image_folder, a.image_format, a.saved_model_filepath, a.output_folder, a.min_box_size)
+    inference(a.image_folder, a.image_format, a.saved_model_filepath, a.output_folder, a.min_box_size, a.precision)

@@ -116,7 +116,7 @@ def inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size=B
     return predictions
 
 
-def inference_image_folder(image_folder, image_format, saved_model_filepath, output_folder, tile_size, min_roi_size):
+def inference_image_folder(image_folder, image_format, saved_model_filepath, output_folder, tile_size, min_roi_size, precision='fp32'):
     if not os.path.exists(saved_model_filepath):
         raise RuntimeError('Missing saved_model_filepath File')
     if image_format.startswith('.'):
@@ -124,6 +124,7 @@ def inference_image_folder(image_folder, image_format, saved_model_filepath, out
     img_filepath_list = [os.path.join(image_folder, fn) for fn in os.listdir(image_folder) if fn.endswith('.{}'.format(image_format))]
     path = os.path.join(saved_model_filepath, 'yolov3.npz') if os.path.isdir(saved_model_filepath) else saved_model_filepath
     yolo = YoloV3.from_file(path)
+    yolo.inference_precision = precision          # 'bf16': bf16 MFMA convs, fp32 heads / decode / NMS (BASELINE config 5)
     if list(tile_size) != list(yolo.img_size[:2]):
         raise RuntimeError('tile size {} must equal the size the model was trained at {} (Q18)'.format(tile_size, yolo.img_size[:2]))
     yolo_model = yolo.get_keras_model()
@@ -148,5 +149,6 @@ if __name__ == '__main__':
     parser.add_argument('--tile-height', type=int, default=512)
     parser.add_argument('--tile-width', type=int, default=512)
     parser.add_argument('--min-box-size', type=int, default=32)
+    parser.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32', help='conv arithmetic (extension; the reference is fp32)')
     a = parser.parse_args()
-    inference_image_folder(a.image_folder, a.image_format, a.saved_model_filepath, a.output_folder, [a.tile_height, a.tile_width], a.min_box_size)
+    inference_image_folder(a.image_folder, a.image_format, a.saved_model_filepath, a.output_folder, [a.tile_height, a.tile_width], a.min_box_size, a.precision)

@@ -51,6 +51,7 @@ SIGNATURES = {
     'y3_transpose_weights_batched': (i32, [fp, fp, ip, i32, i32, vp]),
     'y3_bn_stats_finalize': (i32, [fp, i32, i32, i32, fp, fp, f32, f32, fp, fp, fp, fp, fp, fp, vp]),
     'y3_bn_fold_inference': (i32, [fp, fp, fp, fp, f32, i32, fp, fp, vp]),
+    'y3_bn_fold_inference_batched': (i32, [fp, fp, fp, ip, i32, f32, vp]),
     'y3_bn_apply': (i32, [TP, fp, fp, TP, TP, vp]),
     'y3_bn_bwd_reduce': (i32, [TP, TP, fp, fp, f32, fp, C.POINTER(C.c_int), vp]),
     'y3_bn_bwd_partials': (i32, [i32, i32]),
@@ -59,6 +60,9 @@ SIGNATURES = {
     'y3_upsample_sum2x_fwd': (i32, [TP, TP, vp]),
     'y3_upsample_sum2x_bwd': (i32, [TP, TP, vp]),
     'y3_copy': (i32, [TP, TP, vp]),
+    'y3_conv2d_fwd_bf16': (i32, [TP, vp, fp, i32, i32, TP, i32, u32, f32, fp, fp, TP, vp]),
+    'y3_f32_to_bf16': (i32, [fp, vp, sz, vp]),
+    'y3_upsample_sum2x_fwd_bf16': (i32, [TP, TP, vp]),
     'y3_add_inplace': (i32, [TP, TP, vp]),
     'y3_fill': (i32, [fp, sz, f32, vp]),
     'y3_nchw_to_nhwc': (i32, [fp, i32, i32, i32, i32, TP, vp]),
@@ -90,8 +94,8 @@ def check(rc, what=''):
 
 
 def view(t, n, h, w, c, ld=None, offset=0):
-    """Tensor struct over a torch CUDA tensor's storage (offset in floats)."""
-    return Tensor(t.data_ptr() + 4 * offset, n, h, w, c, c if ld is None else ld)
+    """Tensor struct over a torch CUDA tensor's storage (offset and ld in elements of t's dtype)."""
+    return Tensor(t.data_ptr() + t.element_size() * offset, n, h, w, c, c if ld is None else ld)
 
 
 def float_array(vals):

@@ -166,22 +166,24 @@ class Mean:
 class _Plan:
     """Static launch list for one (batch size, mode)."""
 
-    def __init__(self, model, n, training):
+    def __init__(self, model, n, training, bf16=False):
         self.model = model
         self.n = n
         self.training = training
+        self.bf16 = bool(bf16) and not training     # reduced-precision conv path: inference only (BASELINE config 5)
         self.fwd = []      # [(cfunc, args)]   stream appended at run time
         self.bwd = []
         self.keep = []     # ctypes objects / tensors that must outlive the lists
         self.tensors = []
         self.graph = None
+        self.infer_graph = None
         self._build()
 
     # -- allocation helpers -------------------------------------------------
-    def _new(self, n, h, w, c, ld=None, zero=False):
+    def _new(self, n, h, w, c, ld=None, zero=False, dtype=torch.float32):
         ld = c if ld is None else ld
         numel = n * h * w * ld
-        buf = (torch.zeros if zero else torch.empty)(numel, dtype=torch.float32, device=self.model.device)
+        buf = (torch.zeros if zero else torch.empty)(numel, dtype=dtype, device=self.model.device)
         t = _T(buf, n, h, w, c, ld)
         self.tensors.append(t)      # the launch lists hold raw pointers only: keep every buffer alive with the plan
         return t
@@ -220,6 +222,8 @@ class _Plan:
         specs = mdl.specs
         P = mdl.params
         tr = self.training
+        bf = self.bf16
+        act = torch.bfloat16 if bf else torch.float32      # activation storage type after the first layer
         self.in_nchw = torch.zeros(N, C, H, W, dtype=torch.float32, device=dev)
         self.ops = []      # high-level records for the backward emission
         self.layer_out = []  # output activation of every conv_layer, creation order (debug / tests)
@@ -236,6 +240,10 @@ class _Plan:
         # of the 416 / 608 configurations, the exact need is checked per layer below
         self.conv_ws_bytes = 0
         self._conv_ws_users = []
+        if not tr:
+            # inference-mode BatchNorm (training=False, model.py:38): moving statistics folded into scale / shift, all layers at once
+            self._emit(self.fwd, lib.y3_bn_fold_inference_batched, P.data_ptr(), mdl.moving.data_ptr(), mdl.chan.data_ptr(),
+                       mdl.fold_table().data_ptr(), mdl.fold_layers, BN_EPS)
         if tr:
             self.dz = torch.empty(max_mc, dtype=torch.float32, device=dev)
             self.bnb_ws = torch.empty(512 * 5 * 1024, dtype=torch.float64, device=dev)
@@ -244,13 +252,16 @@ class _Plan:
         def ptr(off):
             return P.data_ptr() + 4 * off
 
+        def wbf(off):
+            return mdl.params_t_bf16.data_ptr() + 2 * off
+
         def conv_layer(src, out=None, resid=None):
             """model.py:29-39 (+ the tf.add of model.py:47 when resid is given)."""
             i = li[0]
             li[0] += 1
             sp = specs[i]
             oh, ow = -(-src.h // sp.s), -(-src.w // sp.s)
-            y = out if out is not None else self._new(N, oh, ow, sp.cout)
+            y = out if out is not None else self._new(N, oh, ow, sp.cout, dtype=act)
             ch = mdl.chan.data_ptr() + 4 * sp.ch_off       # per-layer [scale|shift|mean|rstd|coef(3)] block
             cs = sp.cout * 4
             scale, shift, smean, srstd, coef = ch, ch + cs, ch + 2 * cs, ch + 3 * cs, ch + 4 * cs
@@ -266,8 +277,16 @@ class _Plan:
                            BN_EPS, BN_MOMENTUM, mmean, mvar, smean, srstd, scale, shift)
                 self._emit(self.fwd, lib.y3_bn_apply, a.v, scale, shift, resid.v if resid is not None else None, y.v)
                 self.ops.append(('conv_layer', i, src, a, y, resid, (smean, srstd, coef)))
+            elif bf and i > 0:
+                self._emit(self.fwd, lib.y3_conv2d_fwd_bf16, src.v, wbf(sp.w_off), ptr(sp.b_off), sp.k, sp.s, y.v, 0, EPI_LRELU, LRELU_ALPHA,
+                           scale, shift, resid.v if resid is not None else None)
+            elif bf:
+                # the RGB layer (Cin = 3 padded to 4) stays on the fp32 kernel; its output is rounded to bf16 once
+                y32 = self._new(N, oh, ow, sp.cout)
+                self._conv_call(self.fwd, y.m, sp, lib.y3_conv2d_fwd, src.v, ptr(sp.w_off), ptr(sp.b_off), sp.k, sp.s, y32.v, EPI_LRELU,
+                                LRELU_ALPHA, scale, shift, None, None)
+                self._emit(self.fwd, lib.y3_f32_to_bf16, y32.buf.data_ptr(), y.buf.data_ptr(), y.buf.numel())
             else:
-                self._emit(self.fwd, lib.y3_bn_fold_inference, ptr(sp.g_off), ptr(sp.be_off), mmean, mvar, BN_EPS, sp.cout, scale, shift)
                 self._conv_call(self.fwd, y.m, sp, lib.y3_conv2d_fwd, src.v, ptr(sp.w_off), ptr(sp.b_off), sp.k, sp.s, y.v, EPI_LRELU,
                                 LRELU_ALPHA, scale, shift, resid.v if resid is not None else None, None)
             self.layer_out.append(y)
@@ -292,18 +311,21 @@ class _Plan:
             li[0] += 1
             sp = specs[i]
             fm = self._new(N, src.h, src.w, D, Dld, zero=True)
+            if bf:      # bf16 operands, fp32 feature map: decode / loss / NMS stay fp32
+                self._emit(self.fwd, lib.y3_conv2d_fwd_bf16, src.v, wbf(sp.w_off), ptr(sp.b_off), 1, 1, fm.v, 1, 0, 0.0, None, None, None)
+                return fm
             self._conv_call(self.fwd, fm.m, sp, lib.y3_conv2d_fwd, src.v, ptr(sp.w_off), ptr(sp.b_off), 1, 1, fm.v, 0, 0.0, None, None, None, None)
             self.ops.append(('head', i, src, fm))
             return fm
 
         def upsample_into(src, dst):
-            self._emit(self.fwd, lib.y3_upsample_sum2x_fwd, src.v, dst.v)
+            self._emit(self.fwd, lib.y3_upsample_sum2x_fwd_bf16 if bf else lib.y3_upsample_sum2x_fwd, src.v, dst.v)
             self.ops.append(('upsample', src, dst))
 
         FC = YoloV3.FILTER_COUNT
         g1h, g1w = H // 32, W // 32
-        cat2 = self._new(N, g1h * 2, g1w * 2, FC)              # tf.concat([up(512), route2(512)])  model.py:368
-        cat3 = self._new(N, g1h * 4, g1w * 4, FC // 2)         # tf.concat([up(256), route1(256)])  model.py:375
+        cat2 = self._new(N, g1h * 2, g1w * 2, FC, dtype=act)         # tf.concat([up(512), route2(512)])  model.py:368
+        cat3 = self._new(N, g1h * 4, g1w * 4, FC // 2, dtype=act)    # tf.concat([up(256), route1(256)])  model.py:375
         cat2_up, cat2_rt = cat2.slice(0, FC // 2), cat2.slice(FC // 2, FC // 2)
         cat3_up, cat3_rt = cat3.slice(0, FC // 4), cat3.slice(FC // 4, FC // 4)
 
@@ -485,7 +507,7 @@ class YoloV3:
     WEIGHT_DECAY = 5e-4      # declared by the reference but never applied (Q9)
 
     def __init__(self, global_batch_size, img_size, number_classes, anchors=None, learning_rate=1e-4, device=None, seed=None,
-                 use_graph=False):
+                 use_graph=False, inference_precision='fp32'):
         if not torch.cuda.is_available():
             raise RuntimeError('yolo3.model.YoloV3 needs an MI355X (HIP) device: there is no CPU path')
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
@@ -522,9 +544,15 @@ class YoloV3:
         self.beta1, self.beta2, self.adam_eps = 0.9, 0.999, 1e-7   # Keras Adam defaults (App. C5)
         self.iterations = 0
         self.use_graph = bool(use_graph)
+        if inference_precision not in ('fp32', 'bf16'):
+            raise ValueError("inference_precision must be 'fp32' or 'bf16'")
+        self.inference_precision = inference_precision   # predict() default; training is always fp32
+        self.params_t_bf16 = None                 # bf16 copy of params_t, made on first bf16 predict
+        self._bf16_stale = True
         self.dist = None                          # set by parallel.DataParallel.attach()
         self._plans = {}
         self._tr_table = None
+        self._fold_table = None
         self._init_weights(seed)
         self.model = _CallableModel(self, False)
         self.model_feature_maps = _CallableModel(self, True)
@@ -651,6 +679,24 @@ class YoloV3:
             self._tr_tiles = start
         check(lib.y3_transpose_weights_batched(self.params.data_ptr(), self.params_t.data_ptr(), self._tr_table.data_ptr(), len(self.specs) - 1,
                                                self._tr_tiles, self._stream()), 'y3_transpose_weights_batched')
+        self._bf16_stale = True
+
+    def fold_table(self):
+        """Device table for y3_bn_fold_inference_batched (one row per BatchNorm layer)."""
+        if self._fold_table is None:
+            rows = [[sp.g_off, sp.be_off, sp.mv_off, self.moving_stride + sp.mv_off, sp.ch_off, sp.ch_off + sp.cout, sp.cout]
+                    for sp in self.specs if sp.bn]
+            self.fold_layers = len(rows)
+            self._fold_table = torch.tensor(rows, dtype=torch.int32, device=self.device)
+        return self._fold_table
+
+    def _refresh_bf16(self):
+        """params_t_bf16 <- round-to-nearest-even of params_t (the [tap][Cout][Cin] operand of y3_conv2d_fwd_bf16)."""
+        if self.params_t_bf16 is None:
+            self.params_t_bf16 = torch.zeros(self.arena_floats, dtype=torch.bfloat16, device=self.device)
+        if self._bf16_stale:
+            check(lib.y3_f32_to_bf16(self.params_t.data_ptr(), self.params_t_bf16.data_ptr(), self.arena_floats, self._stream()), 'y3_f32_to_bf16')
+            self._bf16_stale = False
 
     # ---- reference API (model.py:466-479) ---------------------------------------------
     def get_keras_model(self):
@@ -669,10 +715,13 @@ class YoloV3:
         return self.learning_rate
 
     # ---- execution -------------------------------------------------------------------------
-    def _plan(self, n, training):
-        key = (int(n), bool(training))
+    def _plan(self, n, training, bf16=False):
+        bf16 = bool(bf16) and not training
+        key = (int(n), bool(training), bf16)
+        if bf16:
+            self._refresh_bf16()
         if key not in self._plans:
-            self._plans[key] = _Plan(self, int(n), bool(training))
+            self._plans[key] = _Plan(self, int(n), bool(training), bf16)
         return self._plans[key]
 
     def _load_inputs(self, plan, images, gt_data=None):
@@ -685,20 +734,39 @@ class YoloV3:
             for dst, src in zip(plan.gt, gt_data):
                 dst.copy_(torch.as_tensor(src).to(torch.float32).reshape(dst.shape), non_blocking=True)
 
-    def predict(self, images):
-        """The saved 'yolov3' model (model.py:463): NCHW in -> [N, Nb, 5+K]."""
+    def predict(self, images, precision=None):
+        """The saved 'yolov3' model (model.py:463): NCHW in -> [N, Nb, 5+K].  precision 'bf16' runs every conv after
+        the RGB layer on the bf16 MFMA path (fp32 accumulate, fp32 heads / decode); default self.inference_precision."""
         n = int(images.shape[0])
-        plan = self._plan(n, False)
+        plan = self._plan(n, False, (precision or self.inference_precision) == 'bf16')
         self._load_inputs(plan, images)
+        if self.use_graph:
+            if plan.infer_graph is None:
+                self._capture_inference(plan)
+            plan.infer_graph.replay()
+        else:
+            st = self._stream()
+            plan.run_forward(st)
+            plan.run_decode(st)
+        return plan.boxes
+
+    def _capture_inference(self, plan):
+        """forward + decode of one inference plan as a HIP graph (the launch lists are static and read no host state)."""
         st = self._stream()
         plan.run_forward(st)
         plan.run_decode(st)
-        return plan.boxes
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            st = self._stream()
+            plan.run_forward(st)
+            plan.run_decode(st)
+        plan.infer_graph = g
 
-    def feature_maps(self, images, training=False):
-        """The 'yolov3_fm' model (model.py:462): three NCHW feature maps."""
+    def feature_maps(self, images, training=False, precision=None):
+        """The 'yolov3_fm' model (model.py:462): three NCHW feature maps (fp32 unless precision='bf16' is asked for)."""
         n = int(images.shape[0])
-        plan = self._plan(n, training)
+        plan = self._plan(n, training, precision == 'bf16')
         self._load_inputs(plan, images)
         st = self._stream()
         plan.run_forward(st)
@@ -739,6 +807,7 @@ class YoloV3:
         plan = self._plan(n, True)
         self._load_inputs(plan, images, gt_data)
         self.iterations += 1
+        self._bf16_stale = True
         self.lr_t_dev.fill_(self._lr_t())
         st = self._stream()
         if self.use_graph and self.dist is None:

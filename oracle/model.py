@@ -127,6 +127,16 @@ class Net:
             self.p.append(q)
         self.batch_stats = []   # (mean, biased var, count) per BN layer of the last training fwd
         self.trace = None       # optional list of per-layer outputs (NCHW)
+        self.force = None       # optional teacher forcing: {'layers': [NCHW per conv_layer], 'up': [NCHW per upsample]} --
+                                # every layer is still computed (and traced) from its inputs, but the NEXT layer consumes
+                                # the forced tensor, so a per-layer comparison does not compound differences
+        self.trace_exact = None  # like trace, but BEFORE the bf16 rounding (identical to trace when bf16 is off)
+        self.up_trace = None    # optional list of the two upsample outputs (before rounding)
+        self.bf16 = False       # emulate the bf16 inference path: operands of every conv after the first rounded to
+                                # bf16 (round-to-nearest-even), fp32 accumulate / epilogue, one rounding per stored activation
+
+    def _r(self, t):
+        return t.to(torch.bfloat16).to(t.dtype) if self.bf16 else t
 
     def trainable(self):
         out = []
@@ -144,6 +154,8 @@ class Net:
         pw = same_pad(x.shape[3], k, s)
         x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
         w = q['W'].permute(3, 2, 0, 1)            # [kh,kw,Cin,Cout] -> [Cout,Cin,kh,kw]
+        if self.bf16 and i > 0:
+            w = self._r(w)
         z = F.conv2d(x, w, q['b'], stride=s)
         if not sp['bn']:
             return z                               # detection_layer model.py:108-120 (linear)
@@ -155,10 +167,7 @@ class Net:
         else:
             mean, var = q['mean'], q['var']
         y = (a - mean[None, :, None, None]) * torch.rsqrt(var[None, :, None, None] + BN_EPS)
-        y = y * q['gamma'][None, :, None, None] + q['beta'][None, :, None, None]
-        if self.trace is not None:
-            self.trace.append(y.detach())
-        return y
+        return y * q['gamma'][None, :, None, None] + q['beta'][None, :, None, None]
 
     @staticmethod
     def _upsample_2x(x):
@@ -172,16 +181,39 @@ class Net:
         """model.py:356-421 -> (fm1, fm2, fm3) NCHW [N, A*(5+K), G, G]."""
         self.batch_stats = []
         it = iter(range(len(self.specs)))
-        cl = lambda t: self._conv_layer(t, next(it), training)
+        raw = lambda t: self._conv_layer(t, next(it), training)
+        count = [0, 0]
+
+        def done(y):
+            """y = the layer's value after the residual add; the next layer consumes its (bf16-rounded) image."""
+            j = count[0]
+            count[0] += 1
+            if self.trace_exact is not None:
+                self.trace_exact.append(y.detach())
+            y = self._r(y)
+            if self.trace is not None:
+                self.trace.append(y.detach())
+            return self.force['layers'][j].to(y.dtype) if self.force is not None else y
+
+        def cl(t):
+            i = next(it)
+            y = self._conv_layer(t, i, training)
+            return done(y) if self.specs[i]['bn'] else y      # heads stay fp32
+
+        def up(t):
+            y = self._upsample_2x(t)
+            j = count[1]
+            count[1] += 1
+            if self.up_trace is not None:
+                self.up_trace.append(y.detach())      # before rounding, like trace_exact
+            y = self._r(y)
+            return self.force['up'][j].to(y.dtype) if self.force is not None else y
 
         def feature_block(inp, reps):              # model.py:42-48 (Q2: adds the BLOCK input)
             layer = inp
             for _ in range(reps):
                 layer = cl(layer)
-                layer = cl(layer)
-                layer = inp + layer
-                if self.trace is not None:
-                    self.trace[-1] = layer.detach()      # the trace keeps what the next layer consumes
+                layer = done(inp + raw(layer))             # bf16 path: the residual is added before the single rounding
             return layer
 
         def yolo_block(inp):                        # model.py:51-59
@@ -205,11 +237,11 @@ class Net:
         route, x = yolo_block(route3)
         fm1 = cl(x)
         x = cl(route)
-        x = torch.cat([self._upsample_2x(x), route2], dim=1)
+        x = torch.cat([up(x), route2], dim=1)
         route, x = yolo_block(x)
         fm2 = cl(x)
         x = cl(route)
-        x = torch.cat([self._upsample_2x(x), route1], dim=1)
+        x = torch.cat([up(x), route1], dim=1)
         route, x = yolo_block(x)
         fm3 = cl(x)
         return fm1, fm2, fm3

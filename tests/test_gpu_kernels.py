@@ -111,6 +111,88 @@ def test_conv_fwd_fused_inference_epilogue(hip, shape):
     assert_close(dv.cpu().permute(0, 3, 1, 2), ref, rtol=2e-5, what='fused epilogue')
 
 
+BF16_CASES = [
+    # n, h, w, cin, cout, k, s, resid, out_f32
+    (2, 13, 13, 64, 128, 3, 1, True, False),
+    (2, 13, 13, 128, 64, 1, 1, False, False),
+    (2, 26, 26, 32, 64, 3, 2, False, False),
+    (1, 13, 15, 32, 64, 3, 2, False, False),     # odd sizes, stride 2
+    (2, 13, 13, 256, 14, 1, 1, False, True),     # detection head: fp32 out, ragged Cout
+    (2, 128, 128, 32, 128, 3, 1, True, False),   # 128x128 tiles
+    (1, 64, 64, 64, 32, 1, 1, False, False),     # BN=32 tile
+    (3, 20, 20, 64, 64, 3, 1, True, False),      # BN=64 tile, ragged M
+    (1, 13, 13, 512, 1024, 3, 1, True, False),   # long K
+    (1, 26, 26, 768, 256, 1, 1, False, False),   # 1x1 with non-power-of-two Cin (route concat)
+]
+
+
+@pytest.mark.parametrize('case', BF16_CASES)
+def test_conv_fwd_bf16(hip, case):
+    """y3_conv2d_fwd_bf16 vs an fp64 conv over the SAME bf16-rounded operands: products of bf16 pairs are exact in
+    fp32, so the only differences are fp32 accumulation order (<= 2e-5 * max|ref|, as for the fp32 kernel) and, for
+    bf16 outputs, one round-to-nearest-even (half an ulp = 2^-9 relative)."""
+    from util import stream, assert_close
+    n, h, w, cin, cout, k, s, with_resid, out_f32 = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    bf = lambda t: t.to(torch.bfloat16)
+    x = bf(torch.randn(n, cin, h, w, generator=g))
+    wk = bf(torch.randn(k, k, cin, cout, generator=g) * 0.1)
+    b = torch.randn(cout, generator=g)
+    sc = torch.rand(cout, generator=g) + 0.5
+    sh = torch.randn(cout, generator=g)
+    oh, ow = -(-h // s), -(-w // s)
+    r = bf(torch.randn(n, cout, oh, ow, generator=g))
+    sld, dld = cin + 8, (cout + 7) // 8 * 8 + 8
+    sbuf = torch.full((n * h * w * sld + 8,), float('nan'), dtype=torch.bfloat16, device='cuda')
+    sv = torch.as_strided(sbuf, (n, h, w, cin), (h * w * sld, w * sld, sld, 1), 8)
+    sv.copy_(x.permute(0, 2, 3, 1))
+    ddt = torch.float32 if out_f32 else torch.bfloat16
+    dbuf = torch.full((n * oh * ow * dld,), float('nan'), dtype=ddt, device='cuda')
+    dv = dbuf.view(n, oh, ow, dld)[..., :cout]
+    rbuf = r.permute(0, 2, 3, 1).contiguous().cuda()
+    # weights: Keras [kh,kw,ci,co] fp32 -> [kh,kw,co,ci] -> bf16, through the library's own kernels
+    wf = wk.float().contiguous().cuda()
+    wt = torch.empty(k * k * cout * cin, device='cuda')
+    hip.check(hip.lib.y3_transpose_weights(wf.data_ptr(), wt.data_ptr(), k * k, cin, cout, stream()))
+    wtb = torch.empty(k * k * cout * cin, dtype=torch.bfloat16, device='cuda')
+    hip.check(hip.lib.y3_f32_to_bf16(wt.data_ptr(), wtb.data_ptr(), wt.numel(), stream()))
+    assert torch.equal(wtb.view(k, k, cout, cin).cpu(), wk.permute(0, 1, 3, 2))
+    bd, scd, shd = b.cuda(), sc.cuda(), sh.cuda()
+    hip.check(hip.lib.y3_conv2d_fwd_bf16(hip.Tensor(sv.data_ptr(), n, h, w, cin, sld), wtb.data_ptr(), bd.data_ptr(), k, s,
+                                         hip.Tensor(dv.data_ptr(), n, oh, ow, cout, dld), int(out_f32), hip.EPI_LRELU, 0.2,
+                                         scd.data_ptr(), shd.data_ptr(),
+                                         hip.Tensor(rbuf.data_ptr(), n, oh, ow, cout, cout) if with_resid else None, stream()))
+    ref = F.leaky_relu(_conv_ref(x.float(), wk.float(), b, k, s), 0.2) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+    if with_resid:
+        ref = ref + r.double()
+    got = dv.float().cpu().permute(0, 3, 1, 2)
+    if out_f32:
+        assert_close(got, ref, rtol=2e-5, what='bf16 conv (fp32 out)')
+    else:
+        scale = float(ref.abs().max())
+        err = (got.double() - ref).abs()
+        bound = ref.abs() * 2.0 ** -8 + 2e-5 * scale     # half-ulp rounding (2^-9, doubled for slack) + accumulation order
+        assert torch.isfinite(got).all() and bool((err <= bound).all()), 'bf16 conv: max excess %.3e' % float((err - bound).max())
+    assert torch.isnan(dbuf.view(-1, dld)[:, cout:].float()).all(), 'pitch padding overwritten'
+
+
+def test_upsample_and_convert_bf16(hip):
+    from util import stream
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 5, 7, 128, generator=g)
+    xb = x.to(torch.bfloat16).cuda()
+    cv = torch.empty(x.numel(), dtype=torch.bfloat16, device='cuda')
+    hip.check(hip.lib.y3_f32_to_bf16(x.cuda().data_ptr(), cv.data_ptr(), x.numel(), stream()))
+    assert torch.equal(cv.view_as(xb), xb)                    # round-to-nearest-even, same as torch
+    out = torch.full((2, 10, 14, 384), float('nan'), dtype=torch.bfloat16, device='cuda')
+    hip.check(hip.lib.y3_upsample_sum2x_fwd_bf16(hip.Tensor(xb.data_ptr(), 2, 5, 7, 128, 128), hip.Tensor(out.data_ptr(), 2, 10, 14, 128, 384), stream()))
+    ref = xb.double().sum(-1)
+    got = out[..., :128].double()
+    assert torch.isnan(out[..., 128:].float()).all()
+    up = ref.repeat_interleave(2, 1).repeat_interleave(2, 2)[..., None].expand(-1, -1, -1, 128)
+    assert bool(((got - up).abs() <= up.abs() * 2.0 ** -8 + 1e-5).all())
+
+
 DGRAD_CASES = [
     (8, 13, 13, 512, 1024, 3, 1),   # split-K
     (8, 26, 26, 256, 512, 3, 2),    # split-K across the four parity launches

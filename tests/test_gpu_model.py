@@ -85,6 +85,84 @@ def test_inference_matches_oracle(img, n):
     _check(out[..., :4] / den, b32 / den, b64 / den, 'boxes', mult=10.0)
 
 
+def _rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.mark.parametrize('img,n', [(96, 3), (416, 1)])
+def test_bf16_inference_matches_bf16_oracle(img, n):
+    """predict(precision='bf16') (BASELINE config 5's conv path) against the oracle run with the SAME rounding points:
+    bf16 kernels (layers 2..75), one bf16 rounding per stored activation, fp32 accumulation / BN fold / heads / decode.
+    Products of bf16 pairs are exact in fp32, so the two differ only by fp32 summation order -- which can flip a
+    round-to-nearest decision (1 bf16 ulp = 2^-8 on that element).  Yardstick: the distance to the emulation must be
+    no larger than the bf16 path's own distance to the fp32 network (end to end the flips compound through 75 layers;
+    the sharp per-layer statement is test_bf16_layers_teacher_forced below)."""
+    om, params, yolo, images, _ = _setup(img, n, 7, True)
+    out16 = yolo.predict(images.cuda(), precision='bf16').cpu().numpy()
+    fm16 = [f.cpu().numpy() for f in yolo.feature_maps(images.cuda(), precision='bf16')]
+    out32 = yolo.predict(images.cuda()).cpu().numpy()                 # the fp32 plan is untouched by the bf16 one
+    net = om.Net(params, 3, len(ANCHORS), K, dtype=torch.float32)
+    with torch.no_grad():
+        fms32 = [f.numpy() for f in net.feature_maps(images, training=False)]
+        net.bf16 = True
+        fms_e = net.feature_maps(images, training=False)
+        dec_e = om.decode(fms_e, (img, img, 3), ANCHORS, K).numpy()
+        fms_e = [f.numpy() for f in fms_e]
+    assert np.isfinite(out16).all() and out16.shape == out32.shape
+    for i in range(3):
+        d_emul = _rel_l2(fm16[i], fms_e[i])
+        d_prec = _rel_l2(fms_e[i], fms32[i])
+        print('fm%d  bf16-kernel vs bf16-oracle %.3e   bf16-oracle vs fp32-oracle %.3e' % (i + 1, d_emul, d_prec))
+        assert d_emul <= 2.0 * d_prec + 1e-4, (i, d_emul, d_prec)
+        assert d_prec < 0.05                                      # bf16 itself stays a faithful approximation here
+    assert _rel_l2(out16, dec_e) <= 2e-2
+    yolo2 = yolo.__class__(n, [img, img, 3], K, ANCHORS, inference_precision='bf16')
+    yolo2.set_weights(params)
+    assert torch.equal(yolo2.predict(images.cuda()).cpu(), torch.from_numpy(out16))    # constructor default, deterministic
+
+
+def test_bf16_layers_teacher_forced():
+    """Every layer of the bf16 plan on its own: the oracle (fp64 arithmetic, bf16 rounding points) recomputes layer i
+    from the GPU's OWN bf16 inputs (teacher forcing), so nothing compounds.  Bound per element against the oracle's
+    value BEFORE rounding: half a bf16 ulp (round to nearest; a tie or near-tie may legitimately fall either way, which
+    is why the comparison is not against the oracle's rounded value) plus 3e-5 of the layer's scale for fp32
+    accumulation order / the folded BatchNorm affine."""
+    img, n = 96, 2
+    om, params, yolo, images, _ = _setup(img, n, 11, True)
+    yolo.predict(images.cuda(), precision='bf16')
+    plan = yolo._plan(n, False, True)
+    torch.cuda.synchronize()
+    nchw = lambda t: t.torch_view().float().permute(0, 3, 1, 2).cpu()
+    layers = [nchw(t) for t in plan.layer_out]
+    ups = [nchw(op[2]) for op in plan.ops if op[0] == 'upsample']
+    fms_gpu = [f.cpu() for f in yolo.feature_maps(images.cuda(), precision='bf16')]
+    assert len(layers) == 72 and len(ups) == 2
+    net = om.Net(params, 3, len(ANCHORS), K, dtype=torch.float64)
+    net.bf16 = True
+    net.trace_exact, net.up_trace = [], []
+    net.force = {'layers': layers, 'up': ups}
+    with torch.no_grad():
+        fms = net.feature_maps(images.double(), training=False)
+
+    def ok(got, ref, what):
+        got, ref = got.double(), ref.double()
+        ulp = torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)      # bf16: 8 significant bits
+        bound = 0.5 * ulp + 3e-5 * float(ref.abs().max())
+        bad = (got - ref).abs() > bound
+        assert torch.isfinite(got).all() and not bool(bad.any()), '%s: %d elements off, worst excess %.3e' % (
+            what, int(bad.sum()), float(((got - ref).abs() - bound).max()))
+
+    assert len(net.trace_exact) == 72
+    for j, (g, r) in enumerate(zip(layers, net.trace_exact)):
+        ok(g, r, 'conv_layer %d' % j)
+    for j, (g, r) in enumerate(zip(ups, net.up_trace)):
+        ok(g[:, :r.shape[1]], r, 'upsample %d' % j)
+    for j, (g, r) in enumerate(zip(fms_gpu, fms)):
+        assert_fm = (g.double() - r).abs().max() <= 3e-5 * float(r.abs().max())     # fp32 heads: no rounding at all
+        assert bool(assert_fm), 'head %d' % j
+
+
 def test_train_step_matches_oracle():
     """train_step(): forward with batch statistics, loss, full backward (dgrad/wgrad/BN/upsample), Keras Adam,
     moving-stat update.  Step 1 is compared tensor by tensor; step 2 only through its loss, because the first Adam
@@ -156,6 +234,15 @@ def test_test_step_and_graph_replay():
     np.testing.assert_allclose(la, lb, rtol=1e-5)
     for wa, wb in zip(a.trainable_weights(), b.trainable_weights()):
         np.testing.assert_allclose(wa, wb, rtol=0, atol=2.1e-3)
+    # inference graphs (fp32 and bf16 plans) replay to the eager rows, before and after the weights move again
+    for prec in ('fp32', 'bf16'):
+        b.set_weights(a.get_weights())
+        for _ in range(2):
+            ea = a.predict(images.cuda(), precision=prec).clone()
+            gb = b.predict(images.cuda(), precision=prec).clone()
+            assert torch.equal(ea, gb), prec
+            a.train_step((images.cuda(), gt_dev))
+            b.set_weights(a.get_weights())
 
 
 def test_nonsquare_grayscale_three_anchors():
