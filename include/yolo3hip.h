@@ -219,6 +219,15 @@ int y3_nms_single_class(const float* rows5, int m, float iou_thr, int* keep_idx,
 int y3_zscore(const float* in, float* out, int n, size_t count, void* workspace, y3_stream_t stream);
 size_t y3_zscore_workspace_bytes(int n);
 
+/* ---- inference_tiled.convert_image_to_tiles (inference_tiled.py:29-100) on the device -------------
+ * img: HWC image resident in device memory, dtype 0 = uint8, 1 = uint16, 2 = float32.
+ * table_dev: DEVICE int32 [ntiles][6] = {y0, ny, pre_y, x0, nx, pre_x}: tile t is the crop img[y0:y0+ny, x0:x0+nx]
+ * with pre_y / pre_x reflected rows / columns in front and the rest of tile_h / tile_w reflected behind
+ * (np.pad(mode='reflect'), inference_tiled.py:82-92).  out: float32 [ntiles][C][tile_h][tile_w] (astype + transpose,
+ * inference_tiled.py:199-203). */
+int y3_tile_gather(const void* img, int dtype, int height, int width, int channels, const int* table_dev,
+                   int ntiles, int tile_h, int tile_w, float* out, y3_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

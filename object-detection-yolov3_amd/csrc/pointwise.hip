@@ -621,3 +621,46 @@ extern "C" int y3_zscore(const float* in, float* out, int n, size_t count, void*
     Y3_CHECK_LAUNCH("zscore_apply");
     return Y3_OK;
 }
+
+// ---------------------------------------------------------------------------
+// inference_tiled.py:29-100 on the device: crop + np.pad(mode='reflect') + HWC -> CHW + astype(float32) for a batch of tiles.
+// table rows {y0, ny, pre_y, x0, nx, pre_x}: the clamped crop img[y0:y0+ny, x0:x0+nx] and the number of reflected rows /
+// columns in front of it.  numpy's reflect is relative to the CROP (period 2(n-1), no edge repeat), repeated when the
+// pad is longer than the crop.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int reflect_index(int p, int n) {  // p relative to the crop, any sign
+    if (n == 1) return 0;
+    const int period = 2 * (n - 1);
+    int q = p % period;
+    if (q < 0) q += period;
+    return q < n ? q : period - q;
+}
+template <typename T>
+__global__ void tile_gather_kernel(const T* __restrict__ img, int W, int C, const int* __restrict__ table, int th, int tw, float* __restrict__ out) {
+    const int* row = table + blockIdx.z * 6;
+    const int y0 = row[0], ny = row[1], pre_y = row[2], x0 = row[3], nx = row[4], pre_x = row[5];
+    const int y = blockIdx.y;
+    const int sy = y0 + reflect_index(y - pre_y, ny);
+    const T* src = img + (size_t)sy * W * C;
+    float* dst = out + ((size_t)blockIdx.z * C * th + y) * tw;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < tw; x += gridDim.x * blockDim.x) {
+        const int sx = x0 + reflect_index(x - pre_x, nx);
+        for (int c = 0; c < C; ++c) dst[(size_t)c * th * tw + x] = (float)src[(size_t)sx * C + c];
+    }
+}
+extern "C" int y3_tile_gather(const void* img, int dtype, int height, int width, int channels, const int* table_dev, int ntiles, int tile_h,
+                              int tile_w, float* out, y3_stream_t stream) {
+    Y3_CHECK_ARG(img && table_dev && out, "tile_gather: null pointer");
+    Y3_CHECK_ARG(height > 0 && width > 0 && channels > 0 && ntiles > 0 && tile_h > 0 && tile_w > 0, "tile_gather: bad dims");
+    Y3_CHECK_ARG(tile_h <= 65535 && ntiles <= 65535, "tile_gather: grid too large");
+    const dim3 grid(y3_cdiv(tile_w, 256), tile_h, ntiles), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case 0: hipLaunchKernelGGL(tile_gather_kernel<unsigned char>, grid, block, 0, st, (const unsigned char*)img, width, channels, table_dev, tile_h, tile_w, out); break;
+        case 1: hipLaunchKernelGGL(tile_gather_kernel<unsigned short>, grid, block, 0, st, (const unsigned short*)img, width, channels, table_dev, tile_h, tile_w, out); break;
+        case 2: hipLaunchKernelGGL(tile_gather_kernel<float>, grid, block, 0, st, (const float*)img, width, channels, table_dev, tile_h, tile_w, out); break;
+        default: Y3_CHECK_ARG(false, "tile_gather: dtype %d (0 = u8, 1 = u16, 2 = f32)", dtype);
+    }
+    Y3_CHECK_LAUNCH("tile_gather");
+    return Y3_OK;
+}

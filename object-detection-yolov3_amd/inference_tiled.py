@@ -4,8 +4,9 @@ tile -> ghost-band rejection -> global merge -> X,Y,W,H,P,C csv.  Reference: inf
 
 The tile geometry and the merge rules are the reference's, including Q12 (tiles that were reflect-padded on the
 left / top report their clamped origin).  Unlike the reference (one tile per model call, BATCH_SIZE unused at :25) the
-tiles of an image go through the network in batches, are z-scored per tile and NMS'ed on the GPU in one launch per
-batch."""
+image is uploaded once, tiles are cut (reflect padding included) and z-scored on the GPU, go through the network in
+batches and are NMS'ed in one launch per batch.  convert_image_to_tiles stays as the host restatement the device
+tiler is tested against."""
 import argparse
 import os
 
@@ -46,6 +47,43 @@ def convert_image_to_tiles(img, tile_size):
             ys.append(y_st)
             tiles.append(tile)
     return tiles, xs, ys
+
+
+def tile_table(height, width, tile_size):
+    """The tile walk of convert_image_to_tiles as numbers only: rows {y0, ny, pre_y, x0, nx, pre_x} for y3_tile_gather
+    plus the clamped origins (xs, ys) that the merge step uses (Q12)."""
+    radius = [EDGE_EFFECT_RANGE, EDGE_EFFECT_RANGE]
+    assert tile_size[0] % NETWORK_DOWNSAMPLE_FACTOR == 0 and tile_size[1] % NETWORK_DOWNSAMPLE_FACTOR == 0
+    if tile_size[0] >= height:
+        radius[0] = 0
+    if tile_size[1] >= width:
+        radius[1] = 0
+    zone = [tile_size[0] - 2 * radius[0], tile_size[1] - 2 * radius[1]]
+    rows, xs, ys = [], [], []
+    for i in range(0, height, zone[0]):
+        for j in range(0, width, zone[1]):
+            x_st, y_st = j - radius[1], i - radius[0]
+            x_end, y_end = min(j + zone[1] + radius[1], width), min(i + zone[0] + radius[0], height)
+            pre_x, pre_y = max(-x_st, 0), max(-y_st, 0)
+            x_st, y_st = max(x_st, 0), max(y_st, 0)
+            rows.append([y_st, y_end - y_st, pre_y, x_st, x_end - x_st, pre_x])
+            xs.append(x_st)
+            ys.append(y_st)
+    return np.asarray(rows, np.int32), xs, ys
+
+
+_GATHER_DTYPES = {np.dtype(np.uint8): 0, np.dtype(np.uint16): 1, np.dtype(np.float32): 2}
+
+
+def tiles_to_device(img_dev, dtype_code, img_shape, table_dev, t0, count, tile_size):
+    """Tiles t0 .. t0+count of the device-resident HWC image -> float32 [count, C, th, tw] (y3_tile_gather)."""
+    from yolo3._hip import lib, check
+    h, w, c = img_shape
+    out = torch.empty(count, c, tile_size[0], tile_size[1], dtype=torch.float32, device=img_dev.device)
+    st = torch.cuda.current_stream(img_dev.device).cuda_stream
+    check(lib.y3_tile_gather(img_dev.data_ptr(), dtype_code, h, w, c, table_dev.data_ptr() + 24 * t0, count, tile_size[0], tile_size[1],
+                             out.data_ptr(), st), 'y3_tile_gather')
+    return out
 
 
 def merge_tile_detections(boxes, scores, class_label, tile_x, tile_y, tile_size, img_size):
@@ -94,11 +132,18 @@ def inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size=B
     """inference_tiled.py:185-310.  ``yolo_model(batch, training=False)`` maps CUDA float32 [B,C,h,w] (z-scored) to
     rows [B, Nb, 5+K] (CUDA tensor or ndarray)."""
     img_size = img.shape
-    tiles, xs, ys = convert_image_to_tiles(img, tile_size)
+    # the image goes to the GPU once, in its own dtype; cropping, reflect padding, astype(float32) and HWC -> CHW of
+    # convert_image_to_tiles (inference_tiled.py:29-100,199-203) happen there, one launch per batch of tiles
+    img = np.ascontiguousarray(img)
+    if img.dtype not in _GATHER_DTYPES:
+        img = img.astype(np.float32)
+    code = _GATHER_DTYPES[img.dtype]
+    img_dev = torch.from_numpy(img.view(np.int16) if code == 1 else img).cuda()
+    table, xs, ys = tile_table(img_size[0], img_size[1], tile_size)
+    table_dev = torch.from_numpy(table).cuda()
     boxes_list, scores_list, class_label_list = [], [], []
-    for b0 in range(0, len(tiles), batch_size):
-        chunk = tiles[b0:b0 + batch_size]
-        x = torch.from_numpy(np.stack([t.astype(np.float32).transpose((2, 0, 1)) for t in chunk])).cuda()
+    for b0 in range(0, len(xs), batch_size):
+        x = tiles_to_device(img_dev, code, img_size, table_dev, b0, min(batch_size, len(xs) - b0), tile_size)
         x = imagereader.zscore_normalize_device(x)                       # per TILE statistics (inference_tiled.py:205, Q12)
         rows = yolo_model(x, training=False)
         rows = torch.as_tensor(rows, dtype=torch.float32).cuda()

@@ -133,6 +133,39 @@ def test_convert_image_to_tiles_matches_reference(golden_dir):
         assert [t[0:2, 0:2, 0].astype(int).tolist() for t in tiles] == g['corner'], name
 
 
+def _tile_from_table(img, row, tile):
+    """Host statement of y3_tile_gather's indexing (reflect_index in pointwise.hip): crop-relative periodic reflection."""
+    def idx(n_out, start, n, pre):
+        p = np.arange(n_out) - pre
+        if n == 1:
+            return np.full(n_out, start)
+        period = 2 * (n - 1)
+        q = np.mod(p, period)
+        return start + np.where(q < n, q, period - q)
+    y0, ny, pre_y, x0, nx, pre_x = [int(v) for v in row]
+    return img[idx(tile[0], y0, ny, pre_y)][:, idx(tile[1], x0, nx, pre_x)]
+
+
+TILE_CASES = [((417, 1250, 3), [608, 608], 1), ((833, 420, 1), [608, 512], 2), ((300, 200, 3), [512, 512], 3), ((513, 609, 2), [512, 608], 4),
+              ((1249, 418, 1), [608, 608], 5)]
+
+
+def test_tile_table_reproduces_reference_tiles(golden_dir):
+    """tile_table + the device tiler's reflect rule == convert_image_to_tiles (which the goldens pin to the reference),
+    including crops shorter than their padding (np.pad reflects repeatedly) and images smaller than one tile."""
+    import inference_tiled
+    j = json.load(open(os.path.join(golden_dir, 'tiles.json')))
+    cases = [(g['shape'], g['tile'], g['seed']) for g in j.values()] + TILE_CASES
+    for shape, tile, seed in cases:
+        img = np.random.default_rng(seed).integers(0, 256, tuple(shape), dtype=np.uint8)
+        tiles, xs, ys = inference_tiled.convert_image_to_tiles(img, tile)
+        table, txs, tys = inference_tiled.tile_table(shape[0], shape[1], tile)
+        assert txs == xs and tys == ys and len(table) == len(tiles)
+        assert all(t.shape[:2] == tuple(tile) for t in tiles), [t.shape for t in tiles]
+        for t, row in zip(tiles, table):
+            assert np.array_equal(_tile_from_table(img, row, tile), t), (shape, tile, row)
+
+
 def test_tiled_merge_matches_reference(golden_dir):
     """Ghost-band rejection, global shift, rounding and clamping (inference_tiled.py:230-310) against the reference
     run end to end with a deterministic fake model; the per-tile NMS comes from the oracle here (GPU twin: test_gpu_cli.py)."""

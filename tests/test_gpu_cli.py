@@ -39,6 +39,27 @@ def test_tiled_inference_matches_reference_golden(golden_dir):
         assert pred.dtype == np.float64 and np.array_equal(pred, z['pred'])
 
 
+@pytest.mark.parametrize('dtype', [np.uint8, np.uint16, np.float32])
+def test_device_tiler_matches_host_tiler(dtype):
+    """y3_tile_gather (crop + reflect pad + astype(float32) + HWC -> CHW on the GPU) is bit-identical to
+    convert_image_to_tiles, which tests/golden/tiles.json pins to the reference (inference_tiled.py:29-100)."""
+    import inference_tiled
+    from test_cpu_dataplane import TILE_CASES
+    for shape, tile, seed in TILE_CASES + [((1300, 1000, 3), [608, 608], 9)]:
+        rng = np.random.default_rng(seed)
+        img = (rng.standard_normal(shape) * 50).astype(np.float32) if dtype == np.float32 else rng.integers(0, np.iinfo(dtype).max, shape).astype(dtype)
+        tiles, xs, ys = inference_tiled.convert_image_to_tiles(img, tile)
+        table, txs, tys = inference_tiled.tile_table(shape[0], shape[1], tile)
+        code = inference_tiled._GATHER_DTYPES[np.dtype(dtype)]
+        img_dev = torch.from_numpy(img.view(np.int16) if code == 1 else img).cuda()
+        table_dev = torch.from_numpy(table).cuda()
+        for t0 in range(0, len(tiles), 3):
+            cnt = min(3, len(tiles) - t0)
+            got = inference_tiled.tiles_to_device(img_dev, code, shape, table_dev, t0, cnt, tile).cpu().numpy()
+            want = np.stack([t.astype(np.float32).transpose((2, 0, 1)) for t in tiles[t0:t0 + cnt]])
+            assert np.array_equal(got, want), (shape, tile, t0)
+
+
 def _write_dataset(tmp, n, size, K=2, seed=5):
     sys.path.insert(0, PKG)
     import build_lmdb
