@@ -9,6 +9,7 @@
 // Epilogue: + bias -> leaky-relu -> folded BatchNorm affine -> + residual (bf16) -> bf16 (or fp32 for the heads).
 // At 64 bytes of operands per 32 MFMA cycles this kernel is bound by the L2 -> LDS path, not by the matrix pipe.
 #include "common.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
@@ -189,6 +190,92 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
 }
 
 // ---------------------------------------------------------------------------
+// The RGB layer (3x3, stride 1, Cin padded to 4, Cout = 32): K = 36 is far too short for the matrix pipe and the
+// layer is a pure write stream (32 channels out for 4 in), so it is a direct convolution on the vector ALU.  A thread
+// owns 4 consecutive pixels of a row x 8 channels: per input row it loads the 6 float4 pixels its 4 windows cover, and
+// every pair of weights read from LDS (4.5 KB, ds_read_b128 = 4 pairs) feeds 4 packed fp32 FMAs, so the kernel sits on
+// the VALU, not on LDS.  The 4 threads of a pixel write its 64 contiguous bytes of bf16.  fp32 arithmetic throughout,
+// one rounding on the store.  Needs W % 4 == 0 (image sides are multiples of 32).
+// ---------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float* __restrict__ src, int src_ld, const float* __restrict__ wt,
+                                                              const float* __restrict__ bias, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, u16* __restrict__ dst, int dst_ld, int N, int H,
+                                                              int W, unsigned flags, float alpha) {
+    __shared__ __attribute__((aligned(16))) float ws[9 * 4 * 32];
+    for (int i = threadIdx.x; i < 9 * 4 * 32; i += 256) ws[i] = wt[i];
+    __syncthreads();
+    const long long nquad = (long long)N * H * (W >> 2);
+    const long long quad = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
+    if (quad >= nquad) return;
+    const int cg = (threadIdx.x & 3) * 8;
+    const int wq = W >> 2;
+    const long long rowi = quad / wq;               // n * H + oh
+    const int ow0 = (int)(quad - rowi * wq) * 4;
+    const int oh = (int)(rowi % H);
+    f32x2 acc[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[p][c] = f32x2{0.f, 0.f};
+#pragma unroll 1
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh + kh - 1;
+        if ((unsigned)ih >= (unsigned)H) continue;
+        const float* row = src + (rowi + (kh - 1)) * (long long)W * src_ld;
+        float4 x[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int iw = ow0 - 1 + i;
+            x[i] = ((unsigned)iw < (unsigned)W) ? *reinterpret_cast<const float4*>(row + (long long)iw * src_ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const float* w = ws + (kh * 3 + kw) * 128 + cg;
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) {
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(w + ci * 32);
+                const f32x4 wb = *reinterpret_cast<const f32x4*>(w + ci * 32 + 4);
+                const f32x2 w2[4] = {f32x2{wa[0], wa[1]}, f32x2{wa[2], wa[3]}, f32x2{wb[0], wb[1]}, f32x2{wb[2], wb[3]}};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float4 xv = x[p + kw];
+                    const float xs = ci == 0 ? xv.x : ci == 1 ? xv.y : ci == 2 ? xv.z : xv.w;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[p][c] = __builtin_elementwise_fma(f32x2{xs, xs}, w2[c], acc[p][c]);
+                }
+            }
+        }
+    }
+    const bool lrelu = flags & Y3_EPI_LRELU;
+    float eb[8], es[8], ef[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        eb[c] = bias ? bias[cg + c] : 0.f;
+        es[c] = scale ? scale[cg + c] : 1.f;
+        ef[c] = scale ? shift[cg + c] : 0.f;
+    }
+    u16* out = dst + (rowi * W + ow0) * dst_ld + cg;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned packed[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v[2] = {acc[p][c].x, acc[p][c].y};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                v[e] += eb[c * 2 + e];
+                if (lrelu) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
+                if (scale) v[e] = v[e] * es[c * 2 + e] + ef[c * 2 + e];
+            }
+            packed[c] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        }
+        *reinterpret_cast<uint4*>(out + (long long)p * dst_ld) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // small bf16 helpers
 // ---------------------------------------------------------------------------
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, size_t count) {
@@ -309,7 +396,19 @@ extern "C" int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, c
     hipStream_t st = (hipStream_t)stream;
     // tiles: the kernel is load bound, so prefer the largest tile that still gives >= ~2 workgroups per CU
     const long long t128 = (long long)y3_cdiv(p.M, 128) * y3_cdiv(p.Nout, 128);
-    if (p.Nout <= 32) {
+    static const int force = getenv("Y3_BF16_TILE") ? atoi(getenv("Y3_BF16_TILE")) : 0;   // experiments: 1 = 64x64, 2 = 128x128, 3 = 256x128
+    if (force == 1 || (force == 2 && p.Nout >= 128) || (force == 3 && p.Nout >= 128)) {
+        if (force == 1) {
+            p.nbn = y3_cdiv(p.Nout, 64);
+            launch_bf16<64, 64, 2, 2>(p, y3_cdiv(p.M, 64) * p.nbn, st);
+        } else if (force == 2) {
+            p.nbn = y3_cdiv(p.Nout, 128);
+            launch_bf16<128, 128, 2, 2>(p, y3_cdiv(p.M, 128) * p.nbn, st);
+        } else {
+            p.nbn = y3_cdiv(p.Nout, 128);
+            launch_bf16<256, 128, 4, 2>(p, y3_cdiv(p.M, 256) * p.nbn, st);
+        }
+    } else if (p.Nout <= 32) {
         p.nbn = 1;
         launch_bf16<128, 32, 4, 1>(p, y3_cdiv(p.M, 128), st);
     } else if (p.Nout <= 64) {
@@ -323,6 +422,22 @@ extern "C" int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, c
         launch_bf16<64, 64, 2, 2>(p, y3_cdiv(p.M, 64) * p.nbn, st);
     }
     Y3_CHECK_LAUNCH("conv_bf16");
+    return Y3_OK;
+}
+
+extern "C" int y3_conv2d_first_bf16(const y3_tensor* src, const float* wt, const float* bias, const y3_tensor* dst, unsigned flags, float alpha,
+                                    const float* scale, const float* shift, y3_stream_t stream) {
+    Y3_CHECK_ARG(src && src->ptr && dst && dst->ptr && wt, "conv2d_first_bf16: null pointer");
+    Y3_CHECK_ARG(src->c == 4 && dst->c == 32, "conv2d_first_bf16: needs Cin (padded) = 4 and Cout = 32, got %d -> %d", src->c, dst->c);
+    Y3_CHECK_ARG((src->ld & 3) == 0 && ((uintptr_t)src->ptr & 15) == 0 && (dst->ld & 7) == 0 && ((uintptr_t)dst->ptr & 15) == 0,
+                 "conv2d_first_bf16: src must be 16-byte aligned per pixel, dst 16-byte aligned");
+    Y3_CHECK_ARG(dst->n == src->n && dst->h == src->h && dst->w == src->w, "conv2d_first_bf16: dst geometry");
+    Y3_CHECK_ARG((src->w & 3) == 0, "conv2d_first_bf16: width %d must be a multiple of 4", src->w);
+    Y3_CHECK_ARG((scale == nullptr) == (shift == nullptr), "conv2d_first_bf16: scale/shift must both be given");
+    const long long npix = (long long)src->n * src->h * src->w;
+    hipLaunchKernelGGL(conv_first_bf16_kernel, dim3(y3_cdiv(npix / 4, 64)), dim3(256), 0, (hipStream_t)stream, (const float*)src->ptr, src->ld, wt, bias,
+                       scale, shift, (u16*)dst->ptr, dst->ld, src->n, src->h, src->w, flags, alpha);
+    Y3_CHECK_LAUNCH("conv_first_bf16");
     return Y3_OK;
 }
 

@@ -280,8 +280,11 @@ class _Plan:
             elif bf and i > 0:
                 self._emit(self.fwd, lib.y3_conv2d_fwd_bf16, src.v, wbf(sp.w_off), ptr(sp.b_off), sp.k, sp.s, y.v, 0, EPI_LRELU, LRELU_ALPHA,
                            scale, shift, resid.v if resid is not None else None)
+            elif bf and sp.cin_pad == 4 and sp.cout == 32 and sp.k == 3 and sp.s == 1:
+                # the RGB layer: fp32 direct convolution, one rounding on the bf16 store
+                self._emit(self.fwd, lib.y3_conv2d_first_bf16, src.v, ptr(sp.w_off), ptr(sp.b_off), y.v, EPI_LRELU, LRELU_ALPHA, scale, shift)
             elif bf:
-                # the RGB layer (Cin = 3 padded to 4) stays on the fp32 kernel; its output is rounded to bf16 once
+                # (other first-layer shapes) fp32 MFMA kernel, output rounded to bf16 once
                 y32 = self._new(N, oh, ow, sp.cout)
                 self._conv_call(self.fwd, y.m, sp, lib.y3_conv2d_fwd, src.v, ptr(sp.w_off), ptr(sp.b_off), sp.k, sp.s, y32.v, EPI_LRELU,
                                 LRELU_ALPHA, scale, shift, None, None)

@@ -176,6 +176,31 @@ def test_conv_fwd_bf16(hip, case):
     assert torch.isnan(dbuf.view(-1, dld)[:, cout:].float()).all(), 'pitch padding overwritten'
 
 
+def test_conv_first_bf16(hip):
+    """y3_conv2d_first_bf16 (direct fp32 convolution of the RGB layer, bf16 store) vs fp64: half a bf16 ulp + 1e-5 of scale."""
+    from util import nhwc_buf, stream
+    n, h, w = 2, 37, 44
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(n, 4, h, w, generator=g)
+    x[:, 3] = 0
+    wk = torch.randn(3, 3, 4, 32, generator=g) * 0.3
+    b, sc, sh = torch.randn(32, generator=g), torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g)
+    _, sv = nhwc_buf(n, h, w, 4)
+    sv.copy_(x.permute(0, 2, 3, 1))
+    dbuf = torch.full((n * h * w * 40,), float('nan'), dtype=torch.bfloat16, device='cuda')
+    wd, bd, scd, shd = wk.contiguous().cuda(), b.cuda(), sc.cuda(), sh.cuda()
+    hip.check(hip.lib.y3_conv2d_first_bf16(hip.Tensor(sv.data_ptr(), n, h, w, 4, 4), wd.data_ptr(), bd.data_ptr(),
+                                           hip.Tensor(dbuf.data_ptr(), n, h, w, 32, 40), hip.EPI_LRELU, 0.2, scd.data_ptr(), shd.data_ptr(), stream()))
+    ref = (F.leaky_relu(_conv_ref(x, wk, b, 3, 1), 0.2) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]).permute(0, 2, 3, 1)
+    got = dbuf.view(n, h, w, 40)[..., :32].double().cpu()
+    ulp = torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)
+    assert bool(((got - ref).abs() <= 0.5 * ulp + 1e-5 * float(ref.abs().max())).all())
+    assert torch.isnan(dbuf.view(n, h, w, 40)[..., 32:].float()).all()
+    with pytest.raises(hip.HipError):
+        hip.check(hip.lib.y3_conv2d_first_bf16(hip.Tensor(sv.data_ptr(), n, h, w, 4, 4), wd.data_ptr(), bd.data_ptr(),
+                                               hip.Tensor(dbuf.data_ptr(), n, h, w, 16, 40), 0, 0.0, None, None, stream()))
+
+
 def test_upsample_and_convert_bf16(hip):
     from util import stream
     g = torch.Generator().manual_seed(3)
