@@ -37,6 +37,37 @@ K = 2
 IMG = 416
 BATCH = 8
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (not the 2:1 sparsity figure)
+
+
+def tiled_4k(use_graph):
+    """BASELINE.json configs[4]: inference_tiled on one synthetic 4096 x 4096 x 3 uint8 image (SURVEY 8d seed 4), 608 x 608
+    tiles (100 of them, 96-px ghost border), random-init weights: upload -> GPU tiling + per-tile z-score -> network in
+    batches of 8 -> decode -> GPU NMS -> host merge.  Times the whole function per image, fp32 and bf16 conv paths."""
+    import contextlib
+    import io
+    import inference_tiled
+    from yolo3.model import YoloV3
+    y = YoloV3(8, [608, 608, 3], K, ANCHORS, seed=1, use_graph=use_graph)
+    big = np.random.default_rng(4).integers(0, 256, (4096, 4096, 3), dtype=np.uint8)
+    tile_fl = conv_flops_per_image(y.specs, 608)[0]
+    out = {'image': [4096, 4096, 3], 'tile': [608, 608], 'tiles': 100, 'batch': 8}
+    for prec in ('fp32', 'bf16'):
+        y.inference_precision = prec
+        mdl = y.get_keras_model()
+        with contextlib.redirect_stdout(io.StringIO()):
+            inference_tiled.inference_image_tiled(mdl, big, [608, 608], 32)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                inference_tiled.inference_image_tiled(mdl, big, [608, 608], 32)
+            torch.cuda.synchronize()
+        t = (time.perf_counter() - t1) / reps
+        out[prec] = {'ms_per_image_end_to_end': t * 1e3, 'tiles_per_s': 100 / t, 'conv_tflops_end_to_end': tile_fl * 100 / t / 1e12}
+    del y
+    torch.cuda.empty_cache()
+    return out
 
 
 def conv_flops_per_image(specs, img):
@@ -137,6 +168,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-tiled', action='store_true', help='skip the tiled 4k x 4k inference measurement (BASELINE.json configs[4])')
     ap.add_argument('--no-inference', action='store_true', help='skip the secondary inference measurement (config: bs=8 fp32 predict + NMS)')
     ap.add_argument('--bucket-mb', type=float, default=32.0)
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
@@ -221,7 +253,7 @@ def main():
 
     # secondary (BASELINE.json configs[1]): inference bs=8 416x416 fp32 -- z-scored batch -> conv stacks with folded BN ->
     # decode -> clip + small-box filter + class-wise NMS, all on the GPU; reported beside the headline metric
-    infer = None
+    infer = infer16 = tiled = None
     if world == 1 and not args.no_inference:
         from yolo3 import bbox_utils
         for _ in range(3):
@@ -242,6 +274,19 @@ def main():
         t_nms = (time.perf_counter() - t1) / n_inf
         infer = {'images_per_s_forward_decode': BATCH / t_fwd, 'ms_forward_decode': t_fwd * 1e3, 'ms_nms_batch8': t_nms * 1e3,
                  'forward_tflops': fwd_fl * BATCH / t_fwd / 1e12, 'forward_frac_of_fp32_mfma_peak': fwd_fl * BATCH / t_fwd / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+        # the same batch on the bf16 conv path (v_mfma_f32_32x32x16_bf16, fp32 accumulate / heads / decode / NMS)
+        for _ in range(3):
+            yolo.predict(images, precision='bf16')
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_inf):
+            yolo.predict(images, precision='bf16')
+        torch.cuda.synchronize()
+        t16 = (time.perf_counter() - t1) / n_inf
+        infer16 = {'images_per_s_forward_decode': BATCH / t16, 'ms_forward_decode': t16 * 1e3, 'forward_tflops': fwd_fl * BATCH / t16 / 1e12,
+                   'forward_frac_of_bf16_mfma_peak': fwd_fl * BATCH / t16 / 1e12 / BF16_MFMA_PEAK_TFLOPS}
+        if not args.no_tiled:
+            tiled = tiled_4k(use_graph)
 
     if rank == 0:
         out = {
@@ -271,6 +316,10 @@ def main():
         }
         if infer is not None:
             out['inference_bs8_fp32'] = infer
+        if infer16 is not None:
+            out['inference_bs8_bf16'] = infer16
+        if tiled is not None:
+            out['tiled_4k_608'] = tiled
         if world > 1:
             out['config']['backend'] = args.backend
             out['replicas_identical'] = True if args.check_replicas else None

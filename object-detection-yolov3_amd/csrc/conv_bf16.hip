@@ -33,7 +33,7 @@ struct Bf16Args {
     int Nout, K, M;
     unsigned flags;
     float alpha;
-    int nbn, out_f32;
+    int nbn, out_f32, vec_ok;
 };
 
 #define Y3_OOB 0x80000000u
@@ -43,7 +43,15 @@ __device__ __forceinline__ u16 f32_to_bf16(float f) {  // round to nearest even;
     return __builtin_bit_cast(u16, (__bf16)f);
 }
 
-template <int BM, int BN, int WM, int WN>
+// largest multiple of tm that divides bm and fits cap rows
+constexpr int stage_rows(int bm, int tm, int cap) {
+    int best = tm;
+    for (int r = tm; r <= bm; r += tm)
+        if (bm % r == 0 && r <= cap) best = r;
+    return best;
+}
+
+template <int BM, int BN, int WM, int WN, bool STAGED>
 __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args p) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int BK = 32;                // bf16 per K step = 64 bytes per row
@@ -52,8 +60,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
     constexpr int A_LOADS = BM * 4 / THREADS, B_LOADS = (BN * 4 + THREADS - 1) / THREADS;
     static_assert(BM * 4 % THREADS == 0 && TM % 32 == 0 && TN % 32 == 0, "tile shape");
 
-    __shared__ __attribute__((aligned(16))) u16 As[2][BM * LDR];
-    __shared__ __attribute__((aligned(16))) u16 Bs[2][BN * LDR];
+    // one LDS block: [2][BM] + [2][BN] operand rows in the main loop, re-used as the fp32 staging tile of the epilogue
+    __shared__ __attribute__((aligned(16))) u16 smem[2 * (BM + BN) * LDR];
+    u16(*As)[BM * LDR] = reinterpret_cast<u16(*)[BM * LDR]>(smem);
+    u16(*Bs)[BN * LDR] = reinterpret_cast<u16(*)[BN * LDR]>(smem + 2 * BM * LDR);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -152,40 +162,122 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
         cur ^= 1;
     }
 
-    // ---- epilogue: D layout col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if constexpr (!STAGED) {
+        // direct epilogue (no residual, 128x128 tiles): a lane stores its own channel of 16 x MB rows, 2 bytes at a time in
+        // 64-byte runs; cheaper than staging when there is nothing to load and keeps the main loop at 3 waves / SIMD
+        const bool do_lrelu = p.flags & Y3_EPI_LRELU;
+        const bool has_scale = p.scale != nullptr;
+        const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
+        const int mrow = m0 + wm * TM + 4 * lh;
+        const unsigned esz = p.out_f32 ? 4u : 2u;
+        const unsigned ldb = (unsigned)p.dst_ld * esz;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int n = n0 + wn * TN + j * 32 + l31;
+            const bool nok = n < p.Nout;
+            const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+            const float sc = (has_scale && nok) ? p.scale[n] : 1.f;
+            const float sf = (has_scale && nok) ? p.shift[n] : 0.f;
+            const unsigned vbase = (unsigned)mrow * ldb + (unsigned)n * esz;
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool ok = nok && mrow + dr < p.M;
+                    float v = acc[i][j][r] + bias;
+                    if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
+                    if (has_scale) v = v * sc + sf;
+                    if (p.out_f32)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_dst, ok ? vbase : Y3_OOB, (unsigned)dr * ldb, 0);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(v), rs_dst, ok ? vbase : Y3_OOB, (unsigned)dr * ldb, 0);
+                }
+            }
+        }
+        return;
+    }
+    // ---- epilogue.  D layout: col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    // A lane owns single channels of scattered rows, so storing from registers would be 2-byte accesses in 64-byte
+    // runs.  Instead the tile goes through LDS as fp32 (bias / lrelu / BN affine already applied) in passes of RPP rows,
+    // and is read back 8 channels per thread: 16-byte residual loads, one rounding, 16-byte stores, full rows of the
+    // tile contiguous in memory.
+    constexpr int SLD = BN + 4;                                    // staged row pitch (floats)
+    constexpr int CAP_ROWS = (int)(sizeof(smem) / (SLD * 4));
+    constexpr int RPP = stage_rows(BM, TM, CAP_ROWS);              // rows per pass: multiple of TM, divides BM
+    constexpr int PASSES = BM / RPP;
+    constexpr int CG = BN / 8;                                     // 8-channel groups per row
+    static_assert(RPP >= TM && BM % RPP == 0, "staging tile");
+    float* stage = reinterpret_cast<float*>(smem);
     const bool do_lrelu = p.flags & Y3_EPI_LRELU;
     const bool has_scale = p.scale != nullptr, has_resid = p.resid != nullptr;
-    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.resid ? p.resid : p.src), 0,
-                                                                           p.resid ? p.resid_bytes : 0u, 0x00020000);
-    const int mrow = m0 + wm * TM + 4 * lh;
-    const unsigned esz = p.out_f32 ? 4u : 2u;
-    const unsigned ldb = (unsigned)p.dst_ld * esz, rldb = (unsigned)p.resid_ld * 2u;
+    float bias[NB], sc[NB], sf[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int n = n0 + wn * TN + j * 32 + l31;
         const bool nok = n < p.Nout;
-        const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
-        const float sc = (has_scale && nok) ? p.scale[n] : 1.f;
-        const float sf = (has_scale && nok) ? p.shift[n] : 0.f;
-        const unsigned vbase = (unsigned)mrow * ldb + (unsigned)n * esz;
-        const unsigned rbase = (unsigned)mrow * rldb + (unsigned)n * 2u;
+        bias[j] = (p.bias && nok) ? p.bias[n] : 0.f;
+        sc[j] = (has_scale && nok) ? p.scale[n] : 1.f;
+        sf[j] = (has_scale && nok) ? p.shift[n] : 0.f;
+    }
+    const char* resid_b = reinterpret_cast<const char*>(p.resid);
+    char* dst_b = reinterpret_cast<char*>(p.dst);
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int row0 = pass * RPP;                               // first tile row of this pass
+        if (wm * TM >= row0 && wm * TM < row0 + RPP) {
 #pragma unroll
-        for (int i = 0; i < MB; ++i) {
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
-                const bool ok = nok && mrow + dr < p.M;
-                float v = acc[i][j][r] + bias;
-                if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
-                if (has_scale) v = v * sc + sf;
-                if (has_resid) v += bf16_to_f32((u16)__builtin_amdgcn_raw_buffer_load_b16(rs_res, ok ? rbase : Y3_OOB, (unsigned)dr * rldb, 0));
-                if (p.out_f32)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_dst, ok ? vbase : Y3_OOB, (unsigned)dr * ldb, 0);
-                else
-                    __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(v), rs_dst, ok ? vbase : Y3_OOB, (unsigned)dr * ldb, 0);
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[i][j][r] + bias[j];
+                        if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
+                        if (has_scale) v = v * sc[j] + sf[j];
+                        stage[(wm * TM - row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + wn * TN + j * 32 + l31] = v;
+                    }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < RPP * CG; idx += THREADS) {
+            const int row = idx / CG, c8 = (idx - row * CG) * 8;
+            const int m = m0 + row0 + row, n = n0 + c8;
+            if (m >= p.M || n >= p.Nout) continue;
+            const float* sp = stage + row * SLD + c8;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(sp), hi = *reinterpret_cast<const f32x4*>(sp + 4);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (p.vec_ok && n + 8 <= p.Nout) {
+                if (has_resid) {
+                    const uint4 rv = *reinterpret_cast<const uint4*>(resid_b + ((size_t)m * p.resid_ld + n) * 2);
+                    const unsigned rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += __uint_as_float(rw[e] << 16);
+                        v[2 * e + 1] += __uint_as_float(rw[e] & 0xffff0000u);
+                    }
+                }
+                if (p.out_f32) {
+                    float* d = reinterpret_cast<float*>(dst_b + ((size_t)m * p.dst_ld + n) * 4);
+                    *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
+                    unsigned pk[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (unsigned)f32_to_bf16(v[2 * e]) | ((unsigned)f32_to_bf16(v[2 * e + 1]) << 16);
+                    *reinterpret_cast<uint4*>(dst_b + ((size_t)m * p.dst_ld + n) * 2) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                }
+            } else {   // ragged channel count (the detection heads) or unaligned pitches: element by element
+                for (int e = 0; e < 8 && n + e < p.Nout; ++e) {
+                    float x = v[e];
+                    if (has_resid) x += bf16_to_f32(p.resid[(size_t)m * p.resid_ld + n + e]);
+                    if (p.out_f32)
+                        reinterpret_cast<float*>(dst_b)[(size_t)m * p.dst_ld + n + e] = x;
+                    else
+                        reinterpret_cast<u16*>(dst_b)[(size_t)m * p.dst_ld + n + e] = f32_to_bf16(x);
+                }
             }
         }
+        if (pass + 1 < PASSES) __syncthreads();
     }
 }
 
@@ -316,9 +408,9 @@ static int check_bf16_tensor(const y3_tensor* t, const char* name) {
     return 0;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool STAGED = true>
 static void launch_bf16(const Bf16Args& p, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, WM, WN>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
+    hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, WM, WN, STAGED>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
 }
 
 extern "C" int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, const float* bias, int ksize, int stride, const y3_tensor* dst,
@@ -393,6 +485,12 @@ extern "C" int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, c
     p.flags = flags;
     p.alpha = alpha;
     p.out_f32 = dst_is_f32;
+    {   // 16-byte epilogue accesses need 16-byte aligned rows
+        const int eb = dst_is_f32 ? 4 : 2;
+        bool ok = ((uintptr_t)dst->ptr & 15) == 0 && ((long long)dst->ld * eb) % 16 == 0;
+        if (resid) ok = ok && ((uintptr_t)resid->ptr & 15) == 0 && (resid->ld & 7) == 0;
+        p.vec_ok = ok ? 1 : 0;
+    }
     hipStream_t st = (hipStream_t)stream;
     // tiles: the kernel is load bound, so prefer the largest tile that still gives >= ~2 workgroups per CU
     const long long t128 = (long long)y3_cdiv(p.M, 128) * y3_cdiv(p.Nout, 128);
@@ -416,7 +514,10 @@ extern "C" int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, c
         launch_bf16<128, 64, 4, 1>(p, y3_cdiv(p.M, 128), st);
     } else if (t128 >= 512) {
         p.nbn = y3_cdiv(p.Nout, 128);
-        launch_bf16<128, 128, 2, 2>(p, y3_cdiv(p.M, 128) * p.nbn, st);
+        if (p.resid)
+            launch_bf16<128, 128, 2, 2, true>(p, y3_cdiv(p.M, 128) * p.nbn, st);
+        else
+            launch_bf16<128, 128, 2, 2, false>(p, y3_cdiv(p.M, 128) * p.nbn, st);
     } else {
         p.nbn = y3_cdiv(p.Nout, 64);
         launch_bf16<64, 64, 2, 2>(p, y3_cdiv(p.M, 64) * p.nbn, st);

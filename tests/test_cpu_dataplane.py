@@ -196,3 +196,28 @@ def test_load_boxes_csv(tmp_path):
     assert a.tolist() == [[1, 2, 3, 4, 0], [10, 20, 30, 40, 1]]
     assert bbox_utils.load_boxes_to_ltrbc(str(p)).tolist() == [[1, 2, 3, 5, 0], [10, 20, 39, 59, 1]]
     assert bbox_utils.load_boxes_to_xywhc(str(tmp_path / 'none.csv')).shape == (0, 5)
+
+
+def test_find_anchor_sizes_recovers_clusters(tmp_path, capsys):
+    """find_anchor_sizes.py:19-51: (H, W) of every box of every csv, k = 2..7, prints score (= -inertia) and centres."""
+    import find_anchor_sizes
+    from yolo3 import bbox_utils
+    rng = np.random.default_rng(0)
+    true = np.array([[40, 30], [120, 200], [300, 280]])             # (H, W)
+    for f in range(4):
+        rows = []
+        for c, (h, w) in enumerate(true):
+            for _ in range(25):
+                rows.append([int(rng.integers(0, 500)), int(rng.integers(0, 500)), int(w + rng.integers(-5, 6)), int(h + rng.integers(-5, 6)), c])
+        bbox_utils.write_boxes_from_xywhc(np.asarray(rows, np.int32), str(tmp_path / ('a%d.csv' % f)))
+    X = find_anchor_sizes.load_sizes(str(tmp_path))
+    assert X.shape == (300, 2)
+    out = find_anchor_sizes.find_anchors(str(tmp_path), seed=1, plot=False)
+    c3 = out[3][np.argsort(out[3][:, 0])]
+    assert np.abs(c3 - true).max() < 2.0
+    text = capsys.readouterr().out
+    assert text.count('score for') == 6 and 'score for 3-means = -' in text
+    centers, labels, inertia = find_anchor_sizes.kmeans(X, 3, np.random.default_rng(2))
+    assert abs(inertia - sum(((X[labels == j] - centers[j]) ** 2).sum() for j in range(3))) < 1e-6
+    with pytest.raises(ValueError):
+        find_anchor_sizes.kmeans(X[:2], 3, rng)
