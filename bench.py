@@ -43,25 +43,25 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (not the 2:1 spa
 def tiled_4k(use_graph):
     """BASELINE.json configs[4]: inference_tiled on one synthetic 4096 x 4096 x 3 uint8 image (SURVEY 8d seed 4), 608 x 608
     tiles (100 of them, 96-px ghost border), random-init weights: upload -> GPU tiling + per-tile z-score -> network in
-    batches of 8 -> decode -> GPU NMS -> host merge.  Times the whole function per image, fp32 and bf16 conv paths."""
+    batches of 25 -> decode -> GPU NMS -> host merge.  Times the whole function per image, fp32 and bf16 conv paths."""
     import contextlib
     import io
     import inference_tiled
     from yolo3.model import YoloV3
-    y = YoloV3(8, [608, 608, 3], K, ANCHORS, seed=1, use_graph=use_graph)
+    y = YoloV3(25, [608, 608, 3], K, ANCHORS, seed=1, use_graph=use_graph)
     big = np.random.default_rng(4).integers(0, 256, (4096, 4096, 3), dtype=np.uint8)
     tile_fl = conv_flops_per_image(y.specs, 608)[0]
-    out = {'image': [4096, 4096, 3], 'tile': [608, 608], 'tiles': 100, 'batch': 8}
+    out = {'image': [4096, 4096, 3], 'tile': [608, 608], 'tiles': 100, 'batch': 25}
     for prec in ('fp32', 'bf16'):
         y.inference_precision = prec
         mdl = y.get_keras_model()
         with contextlib.redirect_stdout(io.StringIO()):
-            inference_tiled.inference_image_tiled(mdl, big, [608, 608], 32)
+            inference_tiled.inference_image_tiled(mdl, big, [608, 608], 32, batch_size=25)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             reps = 3
             for _ in range(reps):
-                inference_tiled.inference_image_tiled(mdl, big, [608, 608], 32)
+                inference_tiled.inference_image_tiled(mdl, big, [608, 608], 32, batch_size=25)
             torch.cuda.synchronize()
         t = (time.perf_counter() - t1) / reps
         out[prec] = {'ms_per_image_end_to_end': t * 1e3, 'tiles_per_s': 100 / t, 'conv_tflops_end_to_end': tile_fl * 100 / t / 1e12}

@@ -10,6 +10,7 @@
 // At 64 bytes of operands per 32 MFMA cycles this kernel is bound by the L2 -> LDS path, not by the matrix pipe.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
@@ -51,14 +52,14 @@ constexpr int stage_rows(int bm, int tm, int cap) {
     return best;
 }
 
-template <int BM, int BN, int WM, int WN, bool STAGED>
+template <int BM, int BN, int WM, int WN, bool STAGED, int BK = 32>
 __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args p) {
     constexpr int THREADS = 64 * WM * WN;
-    constexpr int BK = 32;                // bf16 per K step = 64 bytes per row
-    constexpr int LDR = 40;               // row pitch in u16 (80 bytes: conflict-free 16-byte fragment reads)
+    constexpr int Q = BK / 8;             // 16-byte quads per row and K step (BK = 32: 64-byte rows, 64: 128-byte rows)
+    constexpr int LDR = BK + 8;           // row pitch in u16 (+16 bytes: staggers the 16-byte fragment reads over the banks)
     constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
-    constexpr int A_LOADS = BM * 4 / THREADS, B_LOADS = (BN * 4 + THREADS - 1) / THREADS;
-    static_assert(BM * 4 % THREADS == 0 && TM % 32 == 0 && TN % 32 == 0, "tile shape");
+    constexpr int A_LOADS = BM * Q / THREADS, B_LOADS = (BN * Q + THREADS - 1) / THREADS;
+    static_assert(BM * Q % THREADS == 0 && TM % 32 == 0 && TN % 32 == 0 && (BK == 32 || BK == 64), "tile shape");
 
     // one LDS block: [2][BM] + [2][BN] operand rows in the main loop, re-used as the fp32 staging tile of the epilogue
     __shared__ __attribute__((aligned(16))) u16 smem[2 * (BM + BN) * LDR];
@@ -77,10 +78,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
     const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.wt), 0, p.wt_bytes, 0x00020000);
 
     unsigned a_voff[A_LOADS], a_mask[A_LOADS];
-    const int quad = tid & 3;
+    const int quad = tid & (Q - 1);
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-        const int row = (tid + i * THREADS) >> 2;
+        const int row = (tid + i * THREADS) / Q;
         const int m = m0 + row;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
@@ -101,31 +102,38 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
         const int idx = tid + i * THREADS;
-        const int n = n0 + (idx >> 2);
-        b_voff[i] = (idx < BN * 4 && n < p.Nout) ? (unsigned)(n * p.C + quad * 8) * 2u : Y3_OOB;
+        const int n = n0 + idx / Q;
+        b_voff[i] = (idx < BN * Q && n < p.Nout) ? (unsigned)(n * p.C + quad * 8) * 2u : Y3_OOB;
     }
 
-    f32x4 ra[A_LOADS], rb[B_LOADS];
-    auto gload = [&](int k0) {
+    // two register stages: the loads of K step s go to stage s & 1 and are written to LDS one iteration later, so a load
+    // has a full iteration (all resident waves' MFMAs) plus its own step to land -- with 16x the fp32 MFMA rate a single
+    // step of compute (8 MFMAs per wave) is far shorter than an L2 round trip
+    f32x4 ra[2][A_LOADS], rb[2][B_LOADS];
+    auto gload = [&](int k0, auto stage) {
+        constexpr int S = decltype(stage)::value;
         const int tap = k0 >> p.logC;
         const int cb = k0 & p.cmask;
         const unsigned a_soff = (unsigned)(p.tap_off[tap] + cb * 2);
         const unsigned b_soff = (unsigned)(p.tap_wt[tap] + cb) * 2u;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i)
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, ((a_mask[i] >> tap) & 1u) ? a_voff[i] : Y3_OOB, a_soff, 0);
+            ra[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, ((a_mask[i] >> tap) & 1u) ? a_voff[i] : Y3_OOB, a_soff, 0);
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[i], b_soff, 0);
+        for (int i = 0; i < B_LOADS; ++i) rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[i], b_soff, 0);
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, auto stage) {
+        constexpr int S = decltype(stage)::value;
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) *reinterpret_cast<f32x4*>(&As[buf][((tid + i * THREADS) >> 2) * LDR + quad * 8]) = ra[i];
+        for (int i = 0; i < A_LOADS; ++i) *reinterpret_cast<f32x4*>(&As[buf][((tid + i * THREADS) / Q) * LDR + quad * 8]) = ra[S][i];
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const int idx = tid + i * THREADS;
-            if (BN * 4 % THREADS == 0 || idx < BN * 4) *reinterpret_cast<f32x4*>(&Bs[buf][(idx >> 2) * LDR + quad * 8]) = rb[i];
+            if (BN * Q % THREADS == 0 || idx < BN * Q) *reinterpret_cast<f32x4*>(&Bs[buf][(idx / Q) * LDR + quad * 8]) = rb[S][i];
         }
     };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
 
     f32x16 acc[MB][NB];
 #pragma unroll
@@ -136,17 +144,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = p.K / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    int cur = 0;
-    for (int ks = 0; ks < nk; ++ks) {
-        const bool more = ks + 1 < nk;
-        if (more) gload((ks + 1) * BK);
+    auto compute = [&](int cur) {
         const u16* as = &As[cur][(wm * TM + l31) * LDR + lh * 8];
         const u16* bs = &Bs[cur][(wn * TN + l31) * LDR + lh * 8];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 16; ++kk) {
             bf16x8 av[MB], bv[NB];
 #pragma unroll
             for (int i = 0; i < MB; ++i) av[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * LDR + kk * 16);
@@ -157,9 +159,26 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
 #pragma unroll
                 for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (more) lstore(cur ^ 1);
+    };
+    // every load / LDS store below is unconditional (steps past the end re-load the last step and are never read), so
+    // the compiler's vmcnt bookkeeping stays exact: the store of stage s waits for its 4 loads only, not the 4 newer ones
+    const int klast = p.K - BK;
+    gload(0, S0{});
+    gload(min(BK, klast), S1{});
+    lstore(0, S0{});
+    __syncthreads();
+    for (int ks = 0; ks < nk; ks += 2) {
+        // even step ks: LDS buffer 0; stage 0 is free (stored last iteration), stage 1 holds step ks + 1
+        gload(min((ks + 2) * BK, klast), S0{});
+        compute(0);
+        lstore(1, S1{});
         __syncthreads();
-        cur ^= 1;
+        if (ks + 1 >= nk) break;
+        // odd step ks + 1: LDS buffer 1; stage 1 free, stage 0 holds step ks + 2
+        gload(min((ks + 3) * BK, klast), S1{});
+        compute(1);
+        lstore(0, S0{});
+        __syncthreads();
     }
 
     if constexpr (!STAGED) {
@@ -408,9 +427,9 @@ static int check_bf16_tensor(const y3_tensor* t, const char* name) {
     return 0;
 }
 
-template <int BM, int BN, int WM, int WN, bool STAGED = true>
+template <int BM, int BN, int WM, int WN, bool STAGED = true, int BK = 32>
 static void launch_bf16(const Bf16Args& p, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, WM, WN, STAGED>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
+    hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, WM, WN, STAGED, BK>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
 }
 
 extern "C" int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, const float* bias, int ksize, int stride, const y3_tensor* dst,
@@ -492,27 +511,27 @@ extern "C" int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, c
         p.vec_ok = ok ? 1 : 0;
     }
     hipStream_t st = (hipStream_t)stream;
-    // tiles: the kernel is load bound, so prefer the largest tile that still gives >= ~2 workgroups per CU
-    const long long t128 = (long long)y3_cdiv(p.M, 128) * y3_cdiv(p.Nout, 128);
+    // Tile choice, measured in the network on MI355X (tools/infer_bench.py --layers, batch 8 of 416^2 and 608^2).  With
+    // 16x the fp32 MFMA rate the kernel is bound by how well resident waves cover each other's LDS / L2 latency, not by
+    // the matrix pipe, so the best shape follows the grid size: 256x128 tiles (8 waves, K steps of 64) where that gives
+    // 150-300 workgroups, 128x128 for larger grids, many small 64x64 workgroups (8+ waves / SIMD) for the small-M layers.
+    const bool k64 = p.K % 64 == 0 && (p.ntaps == 1 || p.C % 64 == 0);
     static const int force = getenv("Y3_BF16_TILE") ? atoi(getenv("Y3_BF16_TILE")) : 0;   // experiments: 1 = 64x64, 2 = 128x128, 3 = 256x128
-    if (force == 1 || (force == 2 && p.Nout >= 128) || (force == 3 && p.Nout >= 128)) {
-        if (force == 1) {
-            p.nbn = y3_cdiv(p.Nout, 64);
-            launch_bf16<64, 64, 2, 2>(p, y3_cdiv(p.M, 64) * p.nbn, st);
-        } else if (force == 2) {
-            p.nbn = y3_cdiv(p.Nout, 128);
-            launch_bf16<128, 128, 2, 2>(p, y3_cdiv(p.M, 128) * p.nbn, st);
-        } else {
-            p.nbn = y3_cdiv(p.Nout, 128);
-            launch_bf16<256, 128, 4, 2>(p, y3_cdiv(p.M, 256) * p.nbn, st);
-        }
-    } else if (p.Nout <= 32) {
+    const long long t256 = (long long)y3_cdiv(p.M, 256) * y3_cdiv(p.Nout, 128);
+    const long long t128 = (long long)y3_cdiv(p.M, 128) * y3_cdiv(p.Nout, 128);
+    if (p.Nout <= 32) {
         p.nbn = 1;
         launch_bf16<128, 32, 4, 1>(p, y3_cdiv(p.M, 128), st);
     } else if (p.Nout <= 64) {
         p.nbn = 1;
         launch_bf16<128, 64, 4, 1>(p, y3_cdiv(p.M, 128), st);
-    } else if (t128 >= 512) {
+    } else if (k64 && (force == 3 || (force == 0 && t256 >= 150 && t256 <= 300))) {
+        p.nbn = y3_cdiv(p.Nout, 128);
+        if (p.resid)
+            launch_bf16<256, 128, 4, 2, true, 64>(p, y3_cdiv(p.M, 256) * p.nbn, st);
+        else
+            launch_bf16<256, 128, 4, 2, false, 64>(p, y3_cdiv(p.M, 256) * p.nbn, st);
+    } else if (force == 2 || (force == 0 && t128 >= 512)) {
         p.nbn = y3_cdiv(p.Nout, 128);
         if (p.resid)
             launch_bf16<128, 128, 2, 2, true>(p, y3_cdiv(p.M, 128) * p.nbn, st);

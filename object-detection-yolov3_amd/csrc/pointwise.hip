@@ -27,33 +27,38 @@ static inline bool same_geom(const y3_tensor* a, const y3_tensor* b) { return a-
 // ---------------------------------------------------------------------------
 // BatchNorm training statistics
 // ---------------------------------------------------------------------------
-// block = 32 partial-lanes x 32 channels; fp64 accumulation of the fp32 partials
+// A block owns 4 channels and spreads the partial rows over 512 lanes (x 2 statistics = 1024 threads, one float4 each):
+// C/4 blocks instead of C/32, so the 32- and 64-channel layers at full resolution (10 816 / 2 704 partial rows) are no
+// longer reduced by one or two workgroups.  fp64 accumulation, fixed tree -> deterministic.
 __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const float* __restrict__ stats, int tiles, int C, double inv_count,
                                                                  double bessel, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float eps, float momentum,
                                                                  float* moving_mean, float* moving_var, float* save_mean,
                                                                  float* save_rstd, float* scale, float* shift) {
-    __shared__ double sm[2][32][33];
-    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int t = g; t < tiles; t += 32) {
-            s += (double)stats[((long long)t * 2 + 0) * C + c];
-            q += (double)stats[((long long)t * 2 + 1) * C + c];
-        }
-    sm[0][g][cl] = s;
-    sm[1][g][cl] = q;
+    __shared__ double sm[1024][4];
+    const int which = threadIdx.x & 1, lane = threadIdx.x >> 1;
+    const int c0 = blockIdx.x * 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t = lane; t < tiles; t += 512) {
+        const float4 v = *reinterpret_cast<const float4*>(stats + ((long long)t * 2 + which) * C + c0);
+        acc[0] += (double)v.x;
+        acc[1] += (double)v.y;
+        acc[2] += (double)v.z;
+        acc[3] += (double)v.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm[threadIdx.x][e] = acc[e];
     __syncthreads();
-    if (g == 0 && c < C) {
-        s = 0.0;
-        q = 0.0;
-        for (int i = 0; i < 32; ++i) {
-            s += sm[0][i][cl];
-            q += sm[1][i][cl];
-        }
-        const double mean = s * inv_count;
-        double var = q * inv_count - mean * mean;
+    for (int half = 512; half >= 2; half >>= 1) {      // threads t and t + half hold the same statistic (half is even)
+        if (threadIdx.x < half)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sm[threadIdx.x][e] += sm[threadIdx.x + half][e];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) {
+        const int c = c0 + threadIdx.x;
+        const double mean = sm[0][threadIdx.x] * inv_count;
+        double var = sm[1][threadIdx.x] * inv_count - mean * mean;
         if (var < 0.0) var = 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         const float fmean = (float)mean;
@@ -76,7 +81,8 @@ extern "C" int y3_bn_stats_finalize(const float* stats, int tiles, int c, int co
     Y3_CHECK_ARG(tiles > 0 && c > 0 && count > 0, "bn_stats_finalize: bad sizes");
     Y3_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "bn_stats_finalize: moving stats must both be given");
     const double bessel = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(y3_cdiv(c, 32)), dim3(1024), 0, (hipStream_t)stream, stats, tiles, c, 1.0 / (double)count,
+    Y3_CHECK_ARG((c & 3) == 0 && ((uintptr_t)stats & 15) == 0, "bn_stats_finalize: channels must be a multiple of 4, stats 16-byte aligned");
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c / 4), dim3(1024), 0, (hipStream_t)stream, stats, tiles, c, 1.0 / (double)count,
                        bessel, gamma, beta, eps, momentum, moving_mean, moving_var, save_mean, save_rstd, scale, shift);
     Y3_CHECK_LAUNCH("bn_stats_finalize");
     return Y3_OK;
@@ -251,29 +257,36 @@ extern "C" int y3_bn_bwd_reduce(const y3_tensor* dy, const y3_tensor* a, const f
     return Y3_OK;
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, double inv_count,
-                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                               const float* __restrict__ rstd, float* dgamma, float* dbeta,
-                                                               float* dbias, float* coef) {
-    __shared__ double sm[5][32][33];
-    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double s[5] = {0, 0, 0, 0, 0};
-    if (c < C)
-        for (int t = g; t < nparts; t += 32)
+// A block owns 4 channels: 128 partial-row lanes x 5 sums = 640 threads, each loading 4 doubles per row; C/4 blocks.
+__global__ __launch_bounds__(640) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, double inv_count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, float* dgamma, float* dbeta,
+                                                              float* dbias, float* coef) {
+    __shared__ double sm[5][128][4];
+    const int j = threadIdx.x % 5, lane = threadIdx.x / 5;
+    const int c0 = blockIdx.x * 4;
+    const double* src = reinterpret_cast<const double*>(partials);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t = lane; t < nparts; t += 128) {
+        const double* p = src + ((long long)t * 5 + j) * C + c0;
+        const double2 lo = *reinterpret_cast<const double2*>(p), hi = *reinterpret_cast<const double2*>(p + 2);
+        acc[0] += lo.x;
+        acc[1] += lo.y;
+        acc[2] += hi.x;
+        acc[3] += hi.y;
+    }
 #pragma unroll
-            for (int j = 0; j < 5; ++j) s[j] += reinterpret_cast<const double*>(partials)[((long long)t * 5 + j) * C + c];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) sm[j][g][cl] = s[j];
+    for (int e = 0; e < 4; ++e) sm[j][lane][e] = acc[e];
     __syncthreads();
-    if (g == 0 && c < C) {
+    for (int half = 64; half >= 1; half >>= 1) {
+        if (lane < half)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            double t = 0.0;
-            for (int i = 0; i < 32; ++i) t += sm[j][i][cl];
-            s[j] = t;
-        }
-        const double db = s[0], dg = s[1], sdys = s[2], ss = s[3], sxs = s[4];
+            for (int e = 0; e < 4; ++e) sm[j][lane][e] += sm[j][lane + half][e];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) {
+        const int e = threadIdx.x, c = c0 + e;
+        const double db = sm[0][0][e], dg = sm[1][0][e], sdys = sm[2][0][e], ss = sm[3][0][e], sxs = sm[4][0][e];
         const double ga = gamma[c], r = rstd[c], mu = mean[c];
         // da = ga*r*(dy - db/M - xhat*dg/M);  dz = da*slope;  dbias = sum dz
         dgamma[c] = (float)dg;
@@ -293,7 +306,8 @@ extern "C" int y3_bn_bwd_finalize(const float* partials, int nparts, int c, int 
     (void)alpha;
     Y3_CHECK_ARG(partials && gamma && save_mean && save_rstd && dgamma && dbeta && dbias && coef, "bn_bwd_finalize: null pointer");
     Y3_CHECK_ARG(nparts > 0 && c > 0 && count > 0, "bn_bwd_finalize: bad sizes");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(y3_cdiv(c, 32)), dim3(1024), 0, (hipStream_t)stream, partials, nparts, c,
+    Y3_CHECK_ARG((c & 3) == 0 && ((uintptr_t)partials & 15) == 0, "bn_bwd_finalize: channels must be a multiple of 4, partials 16-byte aligned");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c / 4), dim3(640), 0, (hipStream_t)stream, partials, nparts, c,
                        1.0 / (double)count, gamma, save_mean, save_rstd, dgamma, dbeta, dbias, coef);
     Y3_CHECK_LAUNCH("bn_bwd_finalize");
     return Y3_OK;

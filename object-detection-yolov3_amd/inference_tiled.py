@@ -16,7 +16,7 @@ import torch
 from yolo3 import bbox_utils, imagereader
 from yolo3.model import YoloV3
 
-BATCH_SIZE = 8
+BATCH_SIZE = 25                   # tiles per network launch (the reference declares 8 at :25 and never uses it); 25 = a 4k image in 4 launches
 EDGE_EFFECT_RANGE = 96            # inference_tiled.py:26
 NETWORK_DOWNSAMPLE_FACTOR = 32
 
@@ -161,7 +161,8 @@ def inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size=B
     return predictions
 
 
-def inference_image_folder(image_folder, image_format, saved_model_filepath, output_folder, tile_size, min_roi_size, precision='fp32'):
+def inference_image_folder(image_folder, image_format, saved_model_filepath, output_folder, tile_size, min_roi_size, precision='fp32',
+                           batch_size=BATCH_SIZE):
     if not os.path.exists(saved_model_filepath):
         raise RuntimeError('Missing saved_model_filepath File')
     if image_format.startswith('.'):
@@ -181,7 +182,7 @@ def inference_image_folder(image_folder, image_format, saved_model_filepath, out
         img = imagereader.imread(img_filepath)
         if len(img.shape) == 2:
             img = np.expand_dims(img, -1)
-        predictions = inference_image_tiled(yolo_model, img, tile_size, min_roi_size)
+        predictions = inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size)
         bbox_utils.write_boxes_from_ltrbpc(predictions, os.path.join(output_folder, file_name.replace(image_format, 'csv')))
 
 
@@ -195,5 +196,6 @@ if __name__ == '__main__':
     parser.add_argument('--tile-width', type=int, default=512)
     parser.add_argument('--min-box-size', type=int, default=32)
     parser.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32', help='conv arithmetic (extension; the reference is fp32)')
+    parser.add_argument('--batch-size', type=int, default=BATCH_SIZE, help='tiles per network launch (extension)')
     a = parser.parse_args()
-    inference_image_folder(a.image_folder, a.image_format, a.saved_model_filepath, a.output_folder, [a.tile_height, a.tile_width], a.min_box_size, a.precision)
+    inference_image_folder(a.image_folder, a.image_format, a.saved_model_filepath, a.output_folder, [a.tile_height, a.tile_width], a.min_box_size, a.precision, a.batch_size)
