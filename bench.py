@@ -154,7 +154,8 @@ def cpu_baseline(seed, budget_s=25.0):
         return time.time() - t0
     t1 = run(1, 1)                    # includes first-touch overheads; only used to size the sample
     bs = BATCH if t1 * BATCH <= budget_s else max(1, int(budget_s / max(t1, 1e-3)))
-    steps = 1
+    t = run(bs, 1)                    # warm: allocator and thread pool settled
+    steps = max(1, min(8, int(0.6 * budget_s / max(t, 1e-3))))          # about 10-20 s of CPU work in the timed sample
     t = run(bs, steps)
     return dict(value=bs * steps / t, unit='images/s', cores=cores, kind='port',
                 sample='oracle/model.py train_step (torch-CPU fp32 restatement of model.py:481-508; TensorFlow unavailable), '

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Refresh the judged measurements of a round on the GPU box:  bash tools/profile_round.sh r01
+# Writes under gpurun_out/<tag>/ ; copy the summaries into profiles/ afterwards (tools/traffic_summary.py for the PMC passes).
+set -e -o pipefail
+TAG=${1:-r01}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python bench.py --steps 20 --warmup 5 > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+echo "bench done"
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-inference > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
+echo "stats done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-inference > $OUT/bench_fetch.json 2> $OUT/rocprof_fetch.err
+echo "fetch done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-inference > $OUT/bench_write.json 2> $OUT/rocprof_write.err
+echo "write done"
+python tools/traffic_summary.py $(find $OUT/fetch -name "*counter_collection.csv") $(find $OUT/write -name "*counter_collection.csv") 6 > $OUT/traffic.json
+python tools/layer_times.py > $OUT/layer_times.txt 2>&1
+find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*counter_collection.csv" -size +20M -delete
+ls -la $OUT $OUT/stats
