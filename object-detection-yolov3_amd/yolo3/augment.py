@@ -2,10 +2,11 @@
 (augment_image_box_pair :30-125, augment_boxes :128-189, apply_affine_transformation_boxes :192-272,
 apply_affine_transformation :275-297, crop_to_size :20-27).
 
-CPU pre-processing in the reader processes, as in the reference; it is stochastic and outside the measured path
-(SURVEY 8f N3).  Rescaling uses scipy.ndimage.zoom (bilinear, reflect) where the reference uses
-skimage.transform.rescale -- scikit-image is not available in this image -- so resampled pixels are not bit-equal;
-box arithmetic follows the reference exactly.  Boxes are [n,5] = x, y, w, h, class (top-left corner).
+CPU pre-processing in the reader processes, as in the reference; it is stochastic (draws from the global np.random in
+the reference's order) and outside the measured path.  scikit-image is not available in this image, so
+the rescale of augment.py:277-280 is restated on scipy.ndimage.map_coordinates (rescale_bilinear).  Pinned by
+tests/golden/augment.npz, produced by running the reference's augment.py under seeded np.random: boxes and crop
+offsets identical, pixels to 1e-4 of the 8-bit range.  Boxes are [n,5] = x, y, w, h, class (top-left corner).
 """
 import numpy as np
 import scipy.ndimage
@@ -33,10 +34,8 @@ def jitter_boxes(boxes, location_jitter, size_jitter, img_shape):
     y1 = np.minimum(y + h - 1, img_shape[0] - 1)
     x0, y0 = np.maximum(x, 0), np.maximum(y, 0)
     ww, hh = x1 - x0 + 1, y1 - y0 + 1
-    ok = (ww > 0) & (hh > 0)
-    if not ok.any():
-        return None
-    return np.stack([x0, y0, ww, hh, b[:, 4]], 1)[ok].astype(np.int32)
+    assert np.all(hh > 0) and np.all(ww > 0), 'box with zero or negative size'      # augment.py:180, same failure mode
+    return np.stack([x0, y0, ww, hh, b[:, 4]], 1).astype(np.int32)
 
 
 def transform_boxes(boxes, crop_size, reflect_x, reflect_y, scale_x, scale_y, dx, dy):
@@ -63,11 +62,28 @@ def transform_boxes(boxes, crop_size, reflect_x, reflect_y, scale_x, scale_y, dx
     return np.stack([x0, y0, x1 - x0 + 1, y1 - y0 + 1, cls], 1).astype(np.int32)
 
 
+def rescale_bilinear(img, scale_y, scale_x):
+    """skimage.transform.rescale(img, [scale_y, scale_x(, 1)], mode='reflect', preserve_range=True) as used at
+    augment.py:277-280 (scikit-image is not in this image): output shape round(shape * scale); output pixel centres map to
+    input coordinates (r + 0.5) * in_rows / out_rows - 0.5 (likewise for columns); bilinear; out-of-range samples reflect
+    without repeating the edge (numpy.pad 'reflect' = scipy 'mirror').  Returns float64 like skimage does."""
+    img = np.asarray(img, dtype=np.float64)
+    rows = int(np.round(scale_y * img.shape[0]))
+    cols = int(np.round(scale_x * img.shape[1]))
+    r = (np.arange(rows) + 0.5) * (img.shape[0] / rows) - 0.5
+    c = (np.arange(cols) + 0.5) * (img.shape[1] / cols) - 0.5
+    grid = np.meshgrid(r, c, indexing='ij')
+    if img.ndim == 2:
+        return scipy.ndimage.map_coordinates(img, grid, order=1, mode='mirror')
+    return np.stack([scipy.ndimage.map_coordinates(img[:, :, ch], grid, order=1, mode='mirror') for ch in range(img.shape[2])], axis=2)
+
+
 def transform_image(img, reflect_x, reflect_y, scale_x, scale_y, crop_to):
-    """augment.py:275-297: rescale, random crop to crop_to, flips.  Returns (img, dx, dy)."""
+    """augment.py:275-297: rescale, random crop to crop_to, flips.  Returns (img float64, dx, dy)."""
     if scale_x != 1 or scale_y != 1:
-        zoom = [scale_y, scale_x] + ([1] if img.ndim == 3 else [])
-        img = scipy.ndimage.zoom(img, zoom, order=1, mode='reflect')
+        img = rescale_bilinear(img, scale_y, scale_x)
+    else:
+        img = np.asarray(img, dtype=np.float64)      # skimage's identity rescale also returns float64 (values unchanged to 1e-12)
     dy = dx = 0
     if img.shape[0] - crop_to[0] > 0:
         dy = int(np.random.randint(0, img.shape[0] - crop_to[0]))

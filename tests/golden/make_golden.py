@@ -13,6 +13,8 @@ What is imported and run from /root/reference:
   imagereader.zscore_normalize, ImageReader.__format_boxes   (pure NumPy)
   inference_tiled.{convert_image_to_tiles, inference_image_tiled} driven by a
       deterministic fake model callable (pure NumPy)
+  augment.{augment_boxes, apply_affine_transformation_boxes, apply_affine_transformation,
+           augment_image_box_pair} under a seeded np.random (NumPy + scikit-image + SciPy)
 The modules import tensorflow / lmdb / isg_ai_pb2 at top level although the
 functions above never touch them; empty placeholder modules satisfy those
 imports (TensorFlow itself is NOT available: the network/loss path stays
@@ -246,6 +248,57 @@ def g7_csv():
         json.dump(dict(xywhc=xywhc.tolist(), xywhc_text=ta, ltrbpc=ltrbpc.tolist(), ltrbpc_text=tb), fh)
 
 
+def g8_augment():
+    """augment.py: box jitter, box / image affine helpers with explicit parameters, and the full pair augmentation
+    under a seeded global NumPy RNG (the reference draws from np.random directly)."""
+    import augment
+    out = {}
+    rng = np.random.default_rng(8)
+    boxes = np.stack([rng.integers(0, 300, 12), rng.integers(0, 200, 12), rng.integers(20, 120, 12), rng.integers(20, 100, 12),
+                      rng.integers(0, 3, 12)], 1).astype(np.int32)
+    out['boxes'] = boxes
+    np.random.seed(123)
+    out['jitter'] = augment.augment_boxes(boxes.copy(), 0.05, 0.08, (260, 420))
+    cases = []
+    for i, (rx, ry, sx, sy, dx, dy, crop) in enumerate([(0, 0, 1.0, 1.0, 0, 0, (260, 420)), (1, 0, 1.0, 1.0, 30, 10, (200, 300)),
+                                                        (0, 1, 1.1, 0.9, 25, 5, (180, 320)), (1, 1, 0.8, 1.2, 0, 40, (160, 200)),
+                                                        (0, 0, 1.0, 1.0, 400, 300, (64, 64))]):
+        r = augment.apply_affine_transformation_boxes(boxes.copy(), crop, rx, ry, sx, sy, dx, dy)
+        out['affine_boxes_%d' % i] = np.zeros((0, 5), np.int32) if r is None else r
+        cases.append([rx, ry, sx, sy, dx, dy, list(crop)])
+    out['affine_cases'] = np.asarray([c[:6] for c in cases], np.float64)
+    out['affine_crops'] = np.asarray([c[6] for c in cases], np.int32)
+    img = rng.integers(0, 256, (90, 120, 3)).astype(np.float32)
+    img2 = rng.integers(0, 256, (70, 100)).astype(np.float32)
+    out['img'], out['img2'] = img, img2
+    icases = [(0, 0, 1.0, 1.0, (64, 96)), (1, 1, 1.0, 1.0, (90, 120)), (1, 0, 1.15, 0.9, (64, 96)), (0, 1, 0.85, 1.3, (56, 80))]
+    for i, (rx, ry, sx, sy, crop) in enumerate(icases):
+        np.random.seed(50 + i)
+        I, dx, dy = augment.apply_affine_transformation(img, rx, ry, sx, sy, crop)
+        out['affine_img_%d' % i] = np.asarray(I, np.float32)
+        out['affine_img_%d_dxdy' % i] = np.asarray([dx, dy])
+    np.random.seed(60)
+    I, dx, dy = augment.apply_affine_transformation(img2, 1, 0, 1.2, 0.95, (60, 90))
+    out['affine_img2'] = np.asarray(I, np.float32)
+    out['affine_img2_dxdy'] = np.asarray([dx, dy])
+    out['affine_img_cases'] = np.asarray([c[:4] for c in icases], np.float64)
+    out['affine_img_crops'] = np.asarray([c[4] for c in icases], np.int32)
+    # the whole pair augmentation: no rescale (bit-comparable pixels) and with rescale
+    pair_boxes = np.asarray([[10, 12, 40, 30, 0], [60, 20, 35, 50, 1], [80, 50, 30, 30, 2]], np.int32)
+    out['pair_boxes'] = pair_boxes
+    for i, kw in enumerate([dict(reflection_flag=True, crop_to=(64, 96), noise_augmentation_severity=0.02, scale_augmentation_severity=0,
+                                 blur_augmentation_max_sigma=2, box_size_augmentation_severity=0.03, box_location_jitter_severity=0.03),
+                            dict(reflection_flag=True, crop_to=(64, 96), noise_augmentation_severity=0.02, scale_augmentation_severity=0.1,
+                                 blur_augmentation_max_sigma=2, box_size_augmentation_severity=0.03, box_location_jitter_severity=0.03)]):
+        for seed in (1, 2, 3):
+            np.random.seed(seed)
+            I, b = augment.augment_image_box_pair(img.copy(), pair_boxes.copy(), **kw)
+            out['pair_%d_%d_img' % (i, seed)] = I
+            out['pair_%d_%d_boxes' % (i, seed)] = np.zeros((0, 5), np.int32) if b is None else b
+    np.savez_compressed(os.path.join(HERE, 'augment.npz'), **out)
+    print('augment: %d arrays' % len(out))
+
+
 if __name__ == '__main__':
     g1_nms()
     g2_units()
@@ -254,4 +307,5 @@ if __name__ == '__main__':
     g5_labels()
     g6_zscore()
     g7_csv()
+    g8_augment()
     print('done')

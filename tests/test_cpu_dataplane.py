@@ -221,3 +221,41 @@ def test_find_anchor_sizes_recovers_clusters(tmp_path, capsys):
     assert abs(inertia - sum(((X[labels == j] - centers[j]) ** 2).sum() for j in range(3))) < 1e-6
     with pytest.raises(ValueError):
         find_anchor_sizes.kmeans(X[:2], 3, rng)
+
+
+def test_augment_matches_reference_goldens(golden_dir):
+    """yolo3/augment.py against tests/golden/augment.npz, produced by running the reference's augment.py under seeded
+    np.random (make_golden.py:g8_augment): box jitter, box affine helper and crop offsets IDENTICAL; un-rescaled pixels
+    (incl. noise and blur) identical; rescaled pixels within 5e-3 on the 0..255 range (skimage's rescale restated on
+    scipy.ndimage.map_coordinates)."""
+    from yolo3 import augment
+    z = np.load(os.path.join(golden_dir, 'augment.npz'))
+    boxes = z['boxes']
+    np.random.seed(123)
+    assert np.array_equal(augment.jitter_boxes(boxes.copy(), 0.05, 0.08, (260, 420)), z['jitter'])
+    for i, (c, crop) in enumerate(zip(z['affine_cases'], z['affine_crops'])):
+        rx, ry, sx, sy, dx, dy = c
+        r = augment.transform_boxes(boxes.copy(), tuple(crop), bool(rx), bool(ry), sx, sy, int(dx), int(dy))
+        want = z['affine_boxes_%d' % i]
+        assert (r is None and want.shape[0] == 0) or np.array_equal(r, want), i
+    for i, (c, crop) in enumerate(zip(z['affine_img_cases'], z['affine_img_crops'])):
+        rx, ry, sx, sy = c
+        np.random.seed(50 + i)
+        img, dx, dy = augment.transform_image(z['img'], bool(rx), bool(ry), sx, sy, tuple(crop))
+        assert [dx, dy] == z['affine_img_%d_dxdy' % i].tolist()
+        assert np.abs(img - z['affine_img_%d' % i]).max() <= (1e-6 if sx == 1 and sy == 1 else 5e-3), i
+    np.random.seed(60)
+    img, dx, dy = augment.transform_image(z['img2'], True, False, 1.2, 0.95, (60, 90))          # 2-D image
+    assert [dx, dy] == z['affine_img2_dxdy'].tolist() and np.abs(img - z['affine_img2']).max() <= 5e-3
+    base = dict(reflection_flag=True, crop_to=(64, 96), noise_augmentation_severity=0.02, blur_augmentation_max_sigma=2,
+                box_size_augmentation_severity=0.03, box_location_jitter_severity=0.03)
+    for i, scale in enumerate((0, 0.1)):
+        for seed in (1, 2, 3):
+            np.random.seed(seed)
+            img, b = augment.augment_image_box_pair(z['img'].copy(), z['pair_boxes'].copy(), scale_augmentation_severity=scale, **base)
+            want = z['pair_%d_%d_boxes' % (i, seed)]
+            assert (b is None and want.shape[0] == 0) or np.array_equal(b, want), (i, seed)
+            assert img.dtype == np.float32 and np.abs(img - z['pair_%d_%d_img' % (i, seed)]).max() <= (0.0 if scale == 0 else 5e-3), (i, seed)
+    with pytest.raises(AssertionError):                                  # augment.py:180: a box jittered to nothing aborts
+        np.random.seed(0)
+        augment.jitter_boxes(np.asarray([[500, 10, 3, 3, 0]], np.int32), 0.0, 0.0, (100, 100))
