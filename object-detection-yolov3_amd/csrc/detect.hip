@@ -293,6 +293,26 @@ __device__ __forceinline__ bool nms_suppressed(float kx0, float ky0, float kx1, 
     return !(iou <= thr);  // survivors satisfy iou <= thr; NaN is dropped, as np.where(iou <= thr) drops it
 }
 
+// bbox_utils.compute_iou (bbox_utils.py:200-214): IoU of one corner box against m boxes, same operation order as above
+__global__ void compute_iou_kernel(const float* __restrict__ box, const float* __restrict__ boxes, int m, int ld, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const float kx0 = box[0], ky0 = box[1], kx1 = box[2], ky1 = box[3];
+    const float* b = boxes + (size_t)i * ld;
+    const float x0 = b[0], y0 = b[1], x1 = b[2], y1 = b[3];
+    const float karea = (kx1 - kx0) * (ky1 - ky0), area = (x1 - x0) * (y1 - y0);
+    const float xl = fmaxf(kx0, x0), yt = fmaxf(ky0, y0);
+    const float xr = fminf(kx1, x1), yb = fminf(ky1, y1);
+    const float inter = fmaxf(yb - yt, 0.f) * fmaxf(xr - xl, 0.f);
+    out[i] = inter / ((karea + area) - inter);
+}
+extern "C" int y3_compute_iou(const float* box4, const float* boxes, int m, int ld, float* iou, y3_stream_t stream) {
+    Y3_CHECK_ARG(box4 && boxes && iou && m > 0 && ld >= 4, "compute_iou: bad args");
+    hipLaunchKernelGGL(compute_iou_kernel, dim3(y3_cdiv(m, 256)), dim3(256), 0, (hipStream_t)stream, box4, boxes, m, ld, iou);
+    Y3_CHECK_LAUNCH("compute_iou");
+    return Y3_OK;
+}
+
 template <bool LDS_KEYS>
 __global__ __launch_bounds__(1024) void nms_kernel(const NmsArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

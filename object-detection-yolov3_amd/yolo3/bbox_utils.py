@@ -99,6 +99,21 @@ def single_class_nms(boxes, scores, iou_threshold):
     return [int(v) for v in keep_idx[:int(keep_cnt.item())].cpu().numpy()]
 
 
+def compute_iou(box, boxes, box_area=None, boxes_area=None):
+    """bbox_utils.py:200-214: IoU of one corner box [4] against boxes [M,4] (no +1) on the GPU, float32 in the
+    reference's operation order -> ndarray [M].  box_area / boxes_area are accepted for signature compatibility; the
+    reference only ever passes the areas of these same boxes (bbox_utils.py:232), which the kernel recomputes."""
+    boxes = np.ascontiguousarray(np.asarray(boxes, np.float32).reshape(-1, 4))
+    if boxes.shape[0] == 0:
+        return np.zeros((0,), np.float32)
+    b = torch.from_numpy(np.ascontiguousarray(np.asarray(box, np.float32).reshape(4))).cuda()
+    bb = torch.from_numpy(boxes).cuda()
+    out = torch.empty(boxes.shape[0], dtype=torch.float32, device=bb.device)
+    check(lib.y3_compute_iou(b.data_ptr(), bb.data_ptr(), boxes.shape[0], 4, out.data_ptr(), torch.cuda.current_stream(bb.device).cuda_stream),
+          'y3_compute_iou')
+    return out.cpu().numpy()
+
+
 def filter_small_boxes(boxes, min_size):
     """bbox_utils.py:274-281 (strict '>'); host NumPy like the reference -- the
     CLIs use the fused device path in ``detect`` instead."""
@@ -133,6 +148,15 @@ def write_boxes_from_xywhc(boxes, csv_filename):
         fh.write('X,Y,W,H,C\n')
         for k in range(boxes.shape[0]):
             fh.write('{:d},{:d},{:d},{:d},{:d}\n'.format(int(boxes[k, 0]), int(boxes[k, 1]), int(boxes[k, 2]), int(boxes[k, 3]), int(boxes[k, 4])))
+
+
+def write_boxes_from_ltrbc(boxes, csv_filename):
+    """bbox_utils.py:65-80: [left, top, right, bottom, class] -> X,Y,W,H,C with W = right - left + 1."""
+    with open(csv_filename, 'w') as fh:
+        fh.write('X,Y,W,H,C\n')
+        for k in range(boxes.shape[0]):
+            x, y = boxes[k, 0], boxes[k, 1]
+            fh.write('{:d},{:d},{:d},{:d},{:d}\n'.format(x, y, boxes[k, 2] - x + 1, boxes[k, 3] - y + 1, boxes[k, 4]))
 
 
 def write_boxes_from_ltrbpc(boxes, csv_filename):

@@ -85,6 +85,19 @@ def format_boxes(boxes, image_size, anchors, number_classes):
     return label
 
 
+def inverse_format_boxes(label, batch_id):
+    """imagereader.py:63-76: boxes [n,4] = x, y, w, h (top-left) back from a label tensor [B,G,G,A,5+K], anchor 0 only,
+    in np.nonzero order; modifies the label rows in place like the reference does."""
+    boxes = []
+    ii, jj = np.nonzero(label[batch_id, :, :, 0, 4])
+    for k in range(len(ii)):
+        bb = label[batch_id, ii[k], jj[k], 0, 0:4]
+        bb[0] = bb[0] - int(bb[2] / 2)
+        bb[1] = bb[1] - int(bb[3] / 2)
+        boxes.append(bb)
+    return np.vstack(boxes)
+
+
 def imread(fp):
     """imagereader.py:49-50 (skimage.io.imread there; PIL here).  Returns HWC or HW ndarray."""
     from PIL import Image

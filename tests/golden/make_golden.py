@@ -299,6 +299,28 @@ def g8_augment():
     print('augment: %d arrays' % len(out))
 
 
+def g9_misc():
+    """bbox_utils.write_boxes_from_ltrbc text and imagereader.inverse_format_boxes on a label tensor produced by the
+    reference's own __format_boxes."""
+    rng = np.random.default_rng(9)
+    ltrbc = np.stack([rng.integers(0, 100, 6), rng.integers(0, 100, 6), rng.integers(100, 300, 6), rng.integers(100, 300, 6),
+                      rng.integers(0, 3, 6)], 1).astype(np.int32)
+    with tempfile.TemporaryDirectory() as d:
+        fp = os.path.join(d, 'a.csv')
+        bbox_utils.write_boxes_from_ltrbc(ltrbc, fp)
+        text = open(fp).read()
+    rd = object.__new__(imagereader.ImageReader)
+    rd.anchors = [(64, 384), (384, 64)]
+    rd.image_size = [416, 416, 3]
+    rd.number_classes = 2
+    boxes = np.asarray([[20, 30, 90, 60, 0], [200, 220, 120, 150, 1], [300, 40, 50, 200, 1]], np.int32)
+    l1, l2, l3 = rd._ImageReader__format_boxes(boxes.copy())
+    label = np.stack([l3, l3])          # batch of 2
+    inv = imagereader.inverse_format_boxes(label.copy(), 1)
+    with open(os.path.join(HERE, 'misc.json'), 'w') as fh:
+        json.dump(dict(ltrbc=ltrbc.tolist(), ltrbc_text=text, fmt_boxes=boxes.tolist(), label3_nonzero=np.argwhere(l3[..., 4] > 0).tolist(), inverse=np.asarray(inv).tolist()), fh)
+
+
 if __name__ == '__main__':
     g1_nms()
     g2_units()
@@ -308,4 +330,5 @@ if __name__ == '__main__':
     g6_zscore()
     g7_csv()
     g8_augment()
+    g9_misc()
     print('done')

@@ -526,6 +526,19 @@ def _golden_nms(golden_dir):
     return sorted(glob.glob(os.path.join(golden_dir, 'nms_*.npz')))
 
 
+def test_compute_iou_matches_reference(hip, golden_dir):
+    """bbox_utils.compute_iou on the GPU == the reference's 64 x 64 IoU matrix (nms_units.npz), bit for bit incl. the
+    0/0 -> NaN entries of zero-area boxes and the IoU-exactly-at-threshold pair."""
+    from yolo3 import bbox_utils
+    u = np.load(os.path.join(golden_dir, 'nms_units.npz'))
+    boxes = u['boxes'].astype(np.float32)
+    got = np.stack([bbox_utils.compute_iou(boxes[i], boxes) for i in range(64)])
+    want = u['ious'].astype(np.float32)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(np.nan_to_num(got, nan=-1).view(np.uint32), np.nan_to_num(want, nan=-1).view(np.uint32))
+    assert bbox_utils.compute_iou(boxes[0], np.zeros((0, 4), np.float32)).shape == (0,)
+
+
 def test_nms_matches_reference_goldens(hip, golden_dir):
     """Class-wise NMS kernel vs the outputs of the reference's bbox_utils (tests/golden): keep indices,
     labels and scores must be IDENTICAL (integer / bit-exact)."""
