@@ -295,7 +295,7 @@ struct FastArgs {
 #define Y3_OOB 0x80000000u
 
 template <int BM, int BN, int WM, int WN, int BK, bool DENSE>
-__global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_kernel(const FastArgs p) {
+__device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int bid0) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int LDA = BK + 4;
     constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
@@ -312,7 +312,6 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int bid0 = y3_xcd_remap(blockIdx.x, gridDim.x);
     const int kz = bid0 % p.ksplit;
     const int bid = bid0 / p.ksplit;
     const int bm = bid / p.nbn, bn = bid % p.nbn;
@@ -548,6 +547,26 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_kernel(const 
             if (n < p.Nout) p.stats[((long long)bm * 2 + which) * p.Nout + n] = s;
         }
     }
+}
+
+template <int BM, int BN, int WM, int WN, int BK, bool DENSE>
+__global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_kernel(const FastArgs p) {
+    conv_fast_body<BM, BN, WM, WN, BK, DENSE>(p, y3_xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Up to four independent gather-GEMMs in ONE launch: the (row parity, column parity) classes of a stride-2 data gradient.
+// Each class has its own tap list, K and destination lattice; block ranges [first[c], first[c+1]) select the class.  As
+// separate launches the four small grids ran one after the other, each with its own ramp-up and tail.
+struct FastArgs4 {
+    FastArgs a[4];
+    int first[5];
+};
+template <int BM, int BN, int WM, int WN, int BK>
+__global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_multi_kernel(const FastArgs4 m) {
+    int c = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) c += ((int)blockIdx.x >= m.first[i]) ? 1 : 0;
+    conv_fast_body<BM, BN, WM, WN, BK, false>(m.a[c], y3_xcd_remap((int)blockIdx.x - m.first[c], m.first[c + 1] - m.first[c]));
 }
 
 // Split-K combine + the conv epilogue: v = sum_z slab[z][m][n] + bias -> lrelu -> stats -> affine -> + resid -> (+)= dst.
@@ -1203,6 +1222,42 @@ extern "C" size_t y3_conv2d_dgrad_workspace(const y3_tensor* ddst, int ksize, in
     return best;
 }
 
+// One launch for all parity classes of a stride-2 data gradient; false if the shapes do not qualify (the caller then
+// launches the classes one by one).
+static bool launch_dgrad_multi(const ConvArgs* cls, int ncls, hipStream_t st) {
+    static const int off = env_int("Y3_NO_DGRAD_MULTI", 0);
+    if (off || ncls < 2 || ncls > 4) return false;
+    FastArgs4 m = {};
+    int mmax = 0;
+    for (int c = 0; c < ncls; ++c) mmax = cls[c].M > mmax ? cls[c].M : mmax;
+    const int ntaps_max = cls[0].K / cls[0].C;
+    if (!fast_shape_ok(cls[0].C, cls[0].Nout, cls[0].K, ntaps_max)) return false;
+    TileCfg t = pick_tile(mmax * ncls, cls[0].Nout);   // the classes share one grid: size the tile for their sum
+    if (t.bm == 128 && t.bn == 128) t.bm = 64;   // the 128x128 instantiation of the merged kernel spills (four argument sets live)
+    if (t.bk != 16) return false;
+    int first = 0;
+    for (int c = 0; c < ncls; ++c) {
+        const int ntaps = cls[c].K / cls[c].C;
+        if (!fast_shape_ok(cls[c].C, cls[c].Nout, cls[c].K, ntaps) || !make_fast(cls[c], ntaps, t.bk, &m.a[c])) return false;
+        m.a[c].nbn = y3_cdiv(cls[c].Nout, t.bn);
+        m.a[c].ksplit = 1;
+        m.a[c].kchunk = cls[c].K;
+        m.a[c].slab = nullptr;
+        m.first[c] = first;
+        first += y3_cdiv(cls[c].M, t.bm) * m.a[c].nbn;
+    }
+    for (int c = ncls; c <= 4; ++c) m.first[c] = first;
+    const int key = t.bm * 1000 + t.bn;
+    switch (key) {
+        case 128 * 1000 + 64: hipLaunchKernelGGL((conv_igemm_fast_multi_kernel<128, 64, 4, 1, 16>), dim3(first), dim3(256), 0, st, m); break;
+        case 128 * 1000 + 32: hipLaunchKernelGGL((conv_igemm_fast_multi_kernel<128, 32, 4, 1, 16>), dim3(first), dim3(256), 0, st, m); break;
+        case 64 * 1000 + 64: hipLaunchKernelGGL((conv_igemm_fast_multi_kernel<64, 64, 2, 2, 16>), dim3(first), dim3(256), 0, st, m); break;
+        case 64 * 1000 + 128: hipLaunchKernelGGL((conv_igemm_fast_multi_kernel<64, 128, 2, 2, 16>), dim3(first), dim3(256), 0, st, m); break;
+        default: return false;
+    }
+    return true;
+}
+
 extern "C" int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc, unsigned flags,
                                void* workspace, size_t workspace_bytes, y3_stream_t stream) {
     if (int e = check_tensor(ddst, "conv2d_dgrad ddst")) return e;
@@ -1252,6 +1307,8 @@ extern "C" int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksi
     }
     // stride 2: forward out o reads in[2o + k - pad]; input pixel i = 2q + par receives from the taps with
     // (par + pad - k) even, at o = q + (par + pad - k)/2.  One launch per (row parity, col parity).
+    ConvArgs cls[4];
+    int ncls = 0;
     for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
             ConvArgs p = base;
@@ -1285,8 +1342,21 @@ extern "C" int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksi
                 p.cmask = 0x7fffffff;
             }
             p.K = nt * ddst->c;
-            if (int e = launch_igemm(p, workspace, workspace_bytes, (hipStream_t)stream)) return e;
+            cls[ncls++] = p;
         }
+    // longest contraction first, so that the 4-tap workgroups of a merged launch start before the 1-tap ones
+    for (int i = 1; i < ncls; ++i)
+        for (int j = i; j > 0 && cls[j].K > cls[j - 1].K; --j) {
+            const ConvArgs tmp = cls[j];
+            cls[j] = cls[j - 1];
+            cls[j - 1] = tmp;
+        }
+    if (launch_dgrad_multi(cls, ncls, (hipStream_t)stream)) {
+        Y3_CHECK_LAUNCH("conv_igemm_fast_multi");
+        return Y3_OK;
+    }
+    for (int c = 0; c < ncls; ++c)
+        if (int e = launch_igemm(cls[c], workspace, workspace_bytes, (hipStream_t)stream)) return e;
     return Y3_OK;
 }
 
