@@ -1128,7 +1128,10 @@ static int launch_igemm(const ConvArgs& a, void* workspace, size_t workspace_byt
         case 128 * 10000 + 32 * 10 + 0: launch_cfg<128, 32, 4, 1, 16>(p, grid, st); break;
         case 64 * 10000 + 64 * 10 + 0: launch_cfg<64, 64, 2, 2, 16>(p, grid, st); break;
         case 64 * 10000 + 128 * 10 + 0: launch_cfg<64, 128, 2, 2, 16>(p, grid, st); break;
-        default: y3_set_error("conv: no generic kernel for tile %dx%dx%d", t.bm, t.bn, t.bk); return Y3_EINVAL;
+        default:   // shapes only the fast kernel is instantiated for (forced tiles): the generic 64x64
+            p.nbn = y3_cdiv(p.Nout, 64);
+            launch_cfg<64, 64, 2, 2, 16>(p, y3_cdiv(p.M, 64) * p.nbn, st);
+            break;
     }
     Y3_CHECK_LAUNCH("conv_igemm");
     return Y3_OK;
