@@ -39,6 +39,18 @@ struct Bf16Args {
 
 #define Y3_OOB 0x80000000u
 
+// Development instrumentation (tools/probe/bf16_timing.hip builds this file with -DY3_TIMING): per-workgroup timestamps
+// of the kernel phases.  Compiled out of the product library.
+#ifdef Y3_TIMING
+__device__ unsigned long long* y3_timing_buf = nullptr;
+#define Y3_TSTAMP(i)                                                                                               \
+    do {                                                                                                           \
+        if (y3_timing_buf && threadIdx.x == 0) y3_timing_buf[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define Y3_TSTAMP(i)
+#endif
+
 __device__ __forceinline__ float bf16_to_f32(u16 v) { return __uint_as_float((unsigned)v << 16); }
 __device__ __forceinline__ u16 f32_to_bf16(float f) {  // round to nearest even; NaN stays NaN
     return __builtin_bit_cast(u16, (__bf16)f);
@@ -66,6 +78,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
     u16(*As)[BM * LDR] = reinterpret_cast<u16(*)[BM * LDR]>(smem);
     u16(*Bs)[BN * LDR] = reinterpret_cast<u16(*)[BN * LDR]>(smem + 2 * BM * LDR);
 
+    Y3_TSTAMP(0);
+#ifdef Y3_TIMING
+    if (y3_timing_buf && threadIdx.x == 0) {
+        y3_timing_buf[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+        y3_timing_buf[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+    }
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
@@ -167,6 +186,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
     gload(min(BK, klast), S1{});
     lstore(0, S0{});
     __syncthreads();
+    Y3_TSTAMP(1);
     for (int ks = 0; ks < nk; ks += 2) {
         // even step ks: LDS buffer 0; stage 0 is free (stored last iteration), stage 1 holds step ks + 1
         gload(min((ks + 2) * BK, klast), S0{});
@@ -181,6 +201,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
         __syncthreads();
     }
 
+    Y3_TSTAMP(2);
     if constexpr (!STAGED) {
         // direct epilogue (no residual, 128x128 tiles): a lane stores its own channel of 16 x MB rows, 2 bytes at a time in
         // 64-byte runs; cheaper than staging when there is nothing to load and keeps the main loop at 3 waves / SIMD
@@ -214,6 +235,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
                 }
             }
         }
+#ifdef Y3_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        Y3_TSTAMP(3);
         return;
     }
     // ---- epilogue.  D layout: col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
@@ -298,6 +323,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
         }
         if (pass + 1 < PASSES) __syncthreads();
     }
+#ifdef Y3_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    Y3_TSTAMP(3);
 }
 
 // ---------------------------------------------------------------------------

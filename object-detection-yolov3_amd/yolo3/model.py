@@ -246,7 +246,7 @@ class _Plan:
                        mdl.fold_table().data_ptr(), mdl.fold_layers, BN_EPS)
         if tr:
             self.dz = torch.empty(max_mc, dtype=torch.float32, device=dev)
-            self.bnb_ws = torch.empty(512 * 5 * 1024, dtype=torch.float64, device=dev)
+            self.bnb_ws = torch.empty(512 * 5 * 1024, dtype=torch.float64, device=dev)      # y3_bn_bwd_partials() <= 512 rows of 5 x C doubles
             self.wg_ws_bytes = 0
 
         def ptr(off):
