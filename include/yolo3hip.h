@@ -218,6 +218,10 @@ size_t y3_nms_workspace_bytes(int n, int nb, int num_classes);
 int y3_nms_single_class(const float* rows5, int m, float iou_thr, int* keep_idx, int* keep_cnt,
                         float* keep_score, void* workspace, size_t workspace_bytes, y3_stream_t stream);
 
+/* bbox_utils.filter_small_boxes (bbox_utils.py:274-281): keep_idx[0..*keep_cnt) = indices, in row order, of the rows
+ * [x0,y0,x1,y1,...] (pitch ld floats) with (x1-x0) > min_size and (y1-y0) > min_size (strict, Q19).  keep_idx holds m ints. */
+int y3_filter_small_boxes(const float* rows, int m, int ld, float min_size, int* keep_idx, int* keep_cnt, y3_stream_t stream);
+
 /* bbox_utils.compute_iou (bbox_utils.py:200-214): iou[i] = IoU(box4, boxes[i*ld .. i*ld+3]), corners, no +1, fp32 in the
  * reference's operation order (0/0 -> NaN as in NumPy). */
 int y3_compute_iou(const float* box4, const float* boxes, int m, int ld, float* iou, y3_stream_t stream);

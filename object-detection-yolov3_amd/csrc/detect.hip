@@ -293,6 +293,45 @@ __device__ __forceinline__ bool nms_suppressed(float kx0, float ky0, float kx1, 
     return !(iou <= thr);  // survivors satisfy iou <= thr; NaN is dropped, as np.where(iou <= thr) drops it
 }
 
+// bbox_utils.filter_small_boxes (bbox_utils.py:274-281): indices of the rows with (x1 - x0) > min AND (y1 - y0) > min (strict),
+// in row order.  One 1024-thread workgroup: per-chunk ballots + an exclusive scan over the 16 waves keep the order.
+__global__ __launch_bounds__(1024) void filter_small_kernel(const float* __restrict__ rows, int m, int ld, float min_size, int* __restrict__ idx,
+                                                            int* __restrict__ count) {
+    __shared__ int wave_cnt[16];
+    __shared__ int base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < m; r0 += 1024) {
+        const int r = r0 + threadIdx.x;
+        bool keep = false;
+        if (r < m) {
+            const float* b = rows + (size_t)r * ld;
+            keep = (b[2] - b[0]) > min_size && (b[3] - b[1]) > min_size;
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int wv = 0; wv < wave; ++wv) off += wave_cnt[wv];
+        if (keep) idx[off + __popcll(bal & ((1ull << lane) - 1ull))] = r;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int wv = 0; wv < 16; ++wv) t += wave_cnt[wv];
+            base += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = base;
+}
+extern "C" int y3_filter_small_boxes(const float* rows, int m, int ld, float min_size, int* keep_idx, int* keep_cnt, y3_stream_t stream) {
+    Y3_CHECK_ARG(rows && keep_idx && keep_cnt && m > 0 && ld >= 4, "filter_small_boxes: bad args");
+    hipLaunchKernelGGL(filter_small_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rows, m, ld, min_size, keep_idx, keep_cnt);
+    Y3_CHECK_LAUNCH("filter_small_boxes");
+    return Y3_OK;
+}
+
 // bbox_utils.compute_iou (bbox_utils.py:200-214): IoU of one corner box against m boxes, same operation order as above
 __global__ void compute_iou_kernel(const float* __restrict__ box, const float* __restrict__ boxes, int m, int ld, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

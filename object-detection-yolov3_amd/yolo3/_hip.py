@@ -77,6 +77,7 @@ SIGNATURES = {
     'y3_nms_per_class': (i32, [fp, i32, i32, i32, f32, f32, f32, f32, f32, ip, ip, fp, i32, vp, sz, vp]),
     'y3_nms_workspace_bytes': (sz, [i32, i32, i32]),
     'y3_nms_single_class': (i32, [fp, i32, f32, ip, ip, fp, vp, sz, vp]),
+    'y3_filter_small_boxes': (i32, [fp, i32, i32, f32, ip, ip, vp]),
     'y3_compute_iou': (i32, [fp, fp, i32, i32, fp, vp]),
     'y3_zscore': (i32, [fp, fp, i32, sz, vp, vp]),
     'y3_zscore_workspace_bytes': (sz, [i32]),

@@ -115,11 +115,18 @@ def compute_iou(box, boxes, box_area=None, boxes_area=None):
 
 
 def filter_small_boxes(boxes, min_size):
-    """bbox_utils.py:274-281 (strict '>'); host NumPy like the reference -- the
-    CLIs use the fused device path in ``detect`` instead."""
-    w = boxes[:, 2] - boxes[:, 0]
-    h = boxes[:, 3] - boxes[:, 1]
-    return boxes[np.logical_and(w > min_size, h > min_size), :]
+    """bbox_utils.py:274-281: rows [M, >=4] = x0, y0, x1, y1, ... -> the rows with width AND height strictly greater
+    than min_size, original order.  The selection runs on the GPU (y3_filter_small_boxes); the CLIs use the path fused
+    into the NMS launch (``detect``) instead."""
+    boxes = np.asarray(boxes)
+    if boxes.shape[0] == 0:
+        return boxes
+    rows = torch.from_numpy(np.ascontiguousarray(boxes[:, :4], dtype=np.float32)).cuda()
+    idx = torch.empty(rows.shape[0], dtype=torch.int32, device=rows.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=rows.device)
+    check(lib.y3_filter_small_boxes(rows.data_ptr(), rows.shape[0], 4, float(min_size), idx.data_ptr(), cnt.data_ptr(),
+                                    torch.cuda.current_stream(rows.device).cuda_stream), 'y3_filter_small_boxes')
+    return boxes[idx[:int(cnt.item())].cpu().numpy().astype(np.int64), :]
 
 
 def load_boxes_to_xywhc(filepath):

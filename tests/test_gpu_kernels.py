@@ -526,6 +526,24 @@ def _golden_nms(golden_dir):
     return sorted(glob.glob(os.path.join(golden_dir, 'nms_*.npz')))
 
 
+def test_filter_small_boxes_matches_reference(hip, golden_dir):
+    """bbox_utils.filter_small_boxes on the GPU keeps exactly the rows the reference keeps (strict '>', row order):
+    checked through the goldens' filtered row sets (the reference's own filter output feeds its NMS there)."""
+    from yolo3 import bbox_utils
+    from oracle import nms as onms
+    for path in _golden_nms(golden_dir):
+        z = np.load(path)
+        if 'rows' not in z.files:
+            continue
+        rows, mb = z['rows'], float(z['min_box'])
+        got = bbox_utils.filter_small_boxes(rows, mb)
+        want = onms.filter_small_boxes(rows, mb)          # pinned to the reference by tests/test_cpu_oracle.py
+        assert got.dtype == rows.dtype and np.array_equal(got, want), path
+    edge = np.asarray([[0, 0, 32, 40, 1], [0, 0, 32.0001, 32.0001, 2], [5, 5, 100, 37, 3], [5, 5, 38, 38, 4]], np.float32)
+    assert bbox_utils.filter_small_boxes(edge, 32)[:, 4].tolist() == [2.0, 4.0]
+    assert bbox_utils.filter_small_boxes(np.zeros((0, 7), np.float32), 32).shape == (0, 7)
+
+
 def test_compute_iou_matches_reference(hip, golden_dir):
     """bbox_utils.compute_iou on the GPU == the reference's 64 x 64 IoU matrix (nms_units.npz), bit for bit incl. the
     0/0 -> NaN entries of zero-area boxes and the IoU-exactly-at-threshold pair."""
