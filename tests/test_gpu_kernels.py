@@ -218,6 +218,30 @@ def test_upsample_and_convert_bf16(hip):
     assert bool(((got - up).abs() <= up.abs() * 2.0 ** -8 + 1e-5).all())
 
 
+@pytest.mark.parametrize('shape', [(3, 13, 13, 1024, 14), (2, 26, 26, 512, 14), (8, 52, 52, 256, 14), (1, 7, 9, 64, 16), (2, 13, 13, 256, 7)])
+def test_conv_fwd_detection_head(hip, shape):
+    """detection_layer (model.py:108-120): linear 1x1 conv to <= 16 channels (ragged Cout, pitch 16, no stats / BN fold /
+    residual), with and without the activation; fp64 reference, 2e-5 of max|ref|."""
+    from util import nhwc_buf, stream, assert_close
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wk = torch.randn(1, 1, cin, cout, generator=g) * 0.05
+    b = torch.randn(cout, generator=g)
+    _, sv = nhwc_buf(n, h, w, cin)
+    sv.copy_(x.permute(0, 2, 3, 1))
+    dld = 16
+    dbuf, dv = nhwc_buf(n, h, w, cout, ld=dld)
+    wd, bd = wk.contiguous().cuda(), b.cuda()
+    for flags, ref in ((0, _conv_ref(x, wk, b, 1, 1)), (hip.EPI_LRELU, F.leaky_relu(_conv_ref(x, wk, b, 1, 1), 0.2))):
+        dbuf.fill_(float('nan'))
+        hip.check(hip.lib.y3_conv2d_fwd(hip.Tensor(sv.data_ptr(), n, h, w, cin, cin), wd.data_ptr(), bd.data_ptr(), 1, 1,
+                                        hip.Tensor(dv.data_ptr(), n, h, w, cout, dld), flags, 0.2, None, None, None, None, None, 0, stream()))
+        assert_close(dv.cpu().permute(0, 3, 1, 2), ref, rtol=2e-5, what='head conv')
+        if dld > cout:
+            assert torch.isnan(dbuf.view(-1, dld)[:, cout:]).all()
+
+
 DGRAD_CASES = [
     (8, 13, 13, 512, 1024, 3, 1),   # split-K
     (8, 26, 26, 256, 512, 3, 2),    # split-K across the four parity launches
