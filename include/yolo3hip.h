@@ -241,6 +241,16 @@ size_t y3_zscore_workspace_bytes(int n);
 int y3_tile_gather(const void* img, int dtype, int height, int width, int channels, const int* table_dev,
                    int ntiles, int tile_h, int tile_w, float* out, y3_stream_t stream);
 
+/* ---- gradient exchange: tf.distribute.MirroredStrategy's all-reduce (train.py:38-39, model.py:500,510-515) -------
+ * One process per GPU; SUM over the replicas (the loss is already divided by the global batch, model.py:492).  RCCL over
+ * xGMI underneath (librccl.so is opened on first use).  Rank 0 calls y3_comm_unique_id and hands the 128 bytes to the
+ * other ranks out of band; every rank then calls y3_comm_init with its HIP device current.  The Python host issues the
+ * same collective through torch.distributed (backend "nccl" = RCCL); these are for callers without torch. */
+int y3_comm_unique_id(void* id128);
+int y3_comm_init(const void* id128, int nranks, int rank, void** comm);
+int y3_allreduce_sum_f32(void* comm, float* buf, size_t count, y3_stream_t stream); /* in place, asynchronous on stream */
+int y3_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

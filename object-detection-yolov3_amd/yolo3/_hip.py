@@ -79,6 +79,10 @@ SIGNATURES = {
     'y3_nms_single_class': (i32, [fp, i32, f32, ip, ip, fp, vp, sz, vp]),
     'y3_filter_small_boxes': (i32, [fp, i32, i32, f32, ip, ip, vp]),
     'y3_compute_iou': (i32, [fp, fp, i32, i32, fp, vp]),
+    'y3_comm_unique_id': (i32, [vp]),
+    'y3_comm_init': (i32, [vp, i32, i32, C.POINTER(C.c_void_p)]),
+    'y3_allreduce_sum_f32': (i32, [vp, fp, sz, vp]),
+    'y3_comm_destroy': (i32, [vp]),
     'y3_zscore': (i32, [fp, fp, i32, sz, vp, vp]),
     'y3_zscore_workspace_bytes': (sz, [i32]),
 }

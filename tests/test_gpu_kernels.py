@@ -650,3 +650,27 @@ def test_zscore_matches_reference_goldens(hip, golden_dir):
         got = imagereader.zscore_normalize(z[k])
         assert got.dtype == np.float32 and got.shape == z[k].shape
         np.testing.assert_allclose(got, z[k + '_out'], rtol=2e-6, atol=2e-6)
+
+
+def test_rccl_comm_single_rank(hip):
+    """y3_comm_* (RCCL behind the C ABI): a one-rank communicator -- the most a single-GPU box can host, RCCL allows one
+    rank per device -- sums a gradient-sized buffer with itself (identity), asynchronously on the caller's stream; bad
+    arguments are reported, not crashed on.  The multi-rank exchange is covered by the gloo world-size-2 tests of
+    yolo3.parallel and by bench.py --gpus N on a multi-GPU node."""
+    import ctypes as C
+    from util import stream
+    uid = (C.c_char * 128)()
+    hip.check(hip.lib.y3_comm_unique_id(uid))
+    comm = C.c_void_p()
+    hip.check(hip.lib.y3_comm_init(uid, 1, 0, C.byref(comm)))
+    assert comm.value
+    g = torch.Generator().manual_seed(1)
+    buf = torch.randn(1 << 20, generator=g).cuda()
+    want = buf.clone()
+    hip.check(hip.lib.y3_allreduce_sum_f32(comm, buf.data_ptr(), buf.numel(), stream()))
+    hip.check(hip.lib.y3_allreduce_sum_f32(comm, buf.data_ptr(), 0, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(buf, want)
+    hip.check(hip.lib.y3_comm_destroy(comm))
+    with pytest.raises(hip.HipError):
+        hip.check(hip.lib.y3_comm_init(uid, 2, 5, C.byref(comm)))
