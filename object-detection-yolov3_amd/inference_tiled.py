@@ -142,13 +142,9 @@ def inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size=B
     table, xs, ys = tile_table(img_size[0], img_size[1], tile_size)
     table_dev = torch.from_numpy(table).cuda()
     boxes_list, scores_list, class_label_list = [], [], []
-    for b0 in range(0, len(xs), batch_size):
-        x = tiles_to_device(img_dev, code, img_size, table_dev, b0, min(batch_size, len(xs) - b0), tile_size)
-        x = imagereader.zscore_normalize_device(x)                       # per TILE statistics (inference_tiled.py:205, Q12)
-        rows = yolo_model(x, training=False)
-        rows = torch.as_tensor(rows, dtype=torch.float32).cuda()
-        dets = bbox_utils.detect(rows, min_roi_size)
-        for k, (boxes, scores, class_label, _) in enumerate(dets):
+
+    def merge(collect, b0):
+        for k, (boxes, scores, class_label, _) in enumerate(collect()):
             if boxes is None:
                 continue
             r = merge_tile_detections(boxes, scores, class_label, xs[b0 + k], ys[b0 + k], tile_size, img_size)
@@ -156,6 +152,21 @@ def inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size=B
                 boxes_list.append(r[0])
                 scores_list.append(r[1])
                 class_label_list.append(r[2])
+
+    # two-deep pipeline: the GPU work of a batch (tiling, z-score, network, NMS) is queued before the previous batch's
+    # detections are copied back and merged on the host
+    pending = None
+    for b0 in range(0, len(xs), batch_size):
+        x = tiles_to_device(img_dev, code, img_size, table_dev, b0, min(batch_size, len(xs) - b0), tile_size)
+        x = imagereader.zscore_normalize_device(x)                       # per TILE statistics (inference_tiled.py:205, Q12)
+        rows = yolo_model(x, training=False)
+        rows = torch.as_tensor(rows, dtype=torch.float32).cuda().clone()  # the model's output buffer is reused by the next call
+        collect = bbox_utils.detect_async(rows, min_roi_size)
+        if pending is not None:
+            merge(*pending)
+        pending = (collect, b0)
+    if pending is not None:
+        merge(*pending)
     predictions = finalize_predictions(boxes_list, scores_list, class_label_list, img_size)
     print('Found: {} rois'.format(predictions.shape[0]))
     return predictions

@@ -25,10 +25,11 @@ class _NmsBuffers:
 _cache = {}
 
 
-def nms_device(rows, min_box_size=0.0, iou_threshold=0.3, score_threshold=0.1, clip_wh=None):
+def nms_device(rows, min_box_size=0.0, iou_threshold=0.3, score_threshold=0.1, clip_wh=None, private_outputs=False):
     """rows: CUDA float32 [N, Nb, 5+K].  Returns (keep_idx[N,K,Nb] int32,
     keep_cnt[N,K] int32, keep_score[N,K,Nb]) device tensors; entries beyond
-    keep_cnt are undefined."""
+    keep_cnt are undefined.  The outputs are per-shape cached buffers that the next call overwrites unless
+    private_outputs is set (the workspace is always shared: launches on one stream run in order)."""
     assert rows.is_cuda and rows.dtype == torch.float32 and rows.dim() == 3
     rows = rows.contiguous()
     n, nb, d = rows.shape
@@ -37,36 +38,57 @@ def nms_device(rows, min_box_size=0.0, iou_threshold=0.3, score_threshold=0.1, c
     buf = _cache.get(key)
     if buf is None:
         buf = _cache[key] = _NmsBuffers(n, nb, k, rows.device)
+    if private_outputs:
+        keep_idx, keep_cnt, keep_score = torch.empty_like(buf.keep_idx), torch.zeros_like(buf.keep_cnt), torch.empty_like(buf.keep_score)
+    else:
+        keep_idx, keep_cnt, keep_score = buf.keep_idx, buf.keep_cnt, buf.keep_score
     cw, chh = (float(clip_wh[0]), float(clip_wh[1])) if clip_wh is not None else (-1.0, -1.0)
     st = torch.cuda.current_stream(rows.device).cuda_stream
     check(lib.y3_nms_per_class(rows.data_ptr(), n, nb, k, float(min_box_size), float(score_threshold), float(iou_threshold), cw, chh,
-                               buf.keep_idx.data_ptr(), buf.keep_cnt.data_ptr(), buf.keep_score.data_ptr(), nb, buf.ws.data_ptr(),
+                               keep_idx.data_ptr(), keep_cnt.data_ptr(), keep_score.data_ptr(), nb, buf.ws.data_ptr(),
                                buf.ws_bytes, st), 'y3_nms_per_class')
-    return buf.keep_idx, buf.keep_cnt, buf.keep_score
+    return keep_idx, keep_cnt, keep_score
+
+
+def detect_async(rows, min_box_size, iou_threshold=0.3, score_threshold=0.1, clip_wh=None):
+    """Enqueue clip -> small-box filter -> class-wise NMS for a batch and return a ``collect()`` callable; nothing
+    synchronises until it is called, so the caller can queue the next batch's network first.  ``rows`` must stay
+    untouched until then (pass a clone of a buffer that the next forward overwrites)."""
+    keep_idx, keep_cnt, keep_score = nms_device(rows, min_box_size, iou_threshold, score_threshold, clip_wh, private_outputs=True)
+    n, nb, d = rows.shape
+    k = d - 5
+
+    def collect():
+        cnt = keep_cnt.cpu().numpy()                       # the only synchronisation point besides the final copies
+        out = [(None, None, None, None)] * n
+        total = int(cnt.sum())
+        if total == 0:
+            return out
+        # flat (image, class, slot) positions of every kept entry, class-major inside an image like bbox_utils.py:252-263
+        ii = np.repeat(np.arange(n), cnt.sum(1))
+        cc = np.concatenate([np.repeat(np.arange(k), cnt[i]) for i in range(n)])
+        jj = np.concatenate([np.arange(c) for c in cnt.reshape(-1)])
+        lin = torch.from_numpy((ii * k + cc) * nb + jj).to(rows.device)
+        idx = keep_idx.view(-1)[lin].long()
+        boxes = rows[torch.from_numpy(ii).to(rows.device), idx, 0:4]
+        if clip_wh is not None:
+            boxes[:, 0::2] = boxes[:, 0::2].clamp(0, float(clip_wh[0]))
+            boxes[:, 1::2] = boxes[:, 1::2].clamp(0, float(clip_wh[1]))
+        boxes, sc, idx = boxes.cpu().numpy(), keep_score.view(-1)[lin].cpu().numpy(), idx.cpu().numpy().astype(np.int32)
+        lab = cc.astype('int32')
+        ends = np.cumsum(cnt.sum(1))
+        for i in range(n):
+            a, b = int(ends[i] - cnt[i].sum()), int(ends[i])
+            if b > a:
+                out[i] = (boxes[a:b], sc[a:b], lab[a:b], idx[a:b])
+        return out
+    return collect
 
 
 def detect(rows, min_box_size, iou_threshold=0.3, score_threshold=0.1, clip_wh=None):
     """inference.py:62-79 for a batch: returns, per image, (boxes[M,4], score[M],
     label[M] int32, keep[M] row indices) as NumPy arrays, or (None,)*4."""
-    keep_idx, keep_cnt, keep_score = nms_device(rows, min_box_size, iou_threshold, score_threshold, clip_wh)
-    cnt = keep_cnt.cpu().numpy()
-    n, nb, d = rows.shape
-    k = d - 5
-    out = []
-    for i in range(n):
-        if cnt[i].sum() == 0:
-            out.append((None, None, None, None))
-            continue
-        idx = torch.cat([keep_idx[i, c, :cnt[i, c]] for c in range(k)]).long()
-        sc = torch.cat([keep_score[i, c, :cnt[i, c]] for c in range(k)])
-        lab = np.concatenate([np.ones(cnt[i, c], dtype='int32') * c for c in range(k)])
-        boxes = rows[i, idx, 0:4]
-        if clip_wh is not None:
-            boxes = boxes.clone()
-            boxes[:, 0::2] = boxes[:, 0::2].clamp(0, float(clip_wh[0]))
-            boxes[:, 1::2] = boxes[:, 1::2].clamp(0, float(clip_wh[1]))
-        out.append((boxes.cpu().numpy(), sc.cpu().numpy(), lab, idx.cpu().numpy().astype(np.int32)))
-    return out
+    return detect_async(rows, min_box_size, iou_threshold, score_threshold, clip_wh)()
 
 
 def per_class_nms(boxes, objectness, class_probs, iou_threshold=0.3, score_threshold=0.1):
