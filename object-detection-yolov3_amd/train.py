@@ -23,7 +23,7 @@ READER_COUNT = 3  # per gpu (train.py:16)
 
 
 def train_model(batch_size, test_every_n_steps, train_database_filepath, test_database_filepath, output_folder, early_stopping_count,
-                learning_rate, use_augmentation, max_epochs=None):
+                learning_rate, use_augmentation, max_epochs=None, reader_count=None):
     os.makedirs(output_folder, exist_ok=True)
     anchors = [(64, 384), (384, 64)]
 
@@ -31,7 +31,11 @@ def train_model(batch_size, test_every_n_steps, train_database_filepath, test_da
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     global_batch_size = batch_size * world
-    reader_count = READER_COUNT
+    if reader_count is None:
+        # the reference's 3 readers per GPU feed a TensorFlow step; a 24 ms step with augmentation on (~20 ms of CPU per image)
+        # needs about 8 -- measured with tools/train_throughput.py: 4 readers 192 images/s, 12 readers 337 (GPU bound)
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
+        reader_count = max(READER_COUNT, min(12, (os.cpu_count() or 8) // max(local_world, 1) - 2))
 
     # readers first: their worker processes are forked before this process touches the GPU
     from yolo3 import imagereader
@@ -188,10 +192,11 @@ if __name__ == "__main__":
     parser.add_argument('--output_dir', dest='output_folder', type=str, help='Folder where outputs will be saved (Required)', required=True)
     parser.add_argument('--early_stopping', dest='terminate_after_num_epochs_without_test_loss_improvement', type=int, default=10)
     parser.add_argument('--use_augmentation', dest='use_augmentation', type=int, default=1)
+    parser.add_argument('--reader_count', dest='reader_count', type=int, default=None, help='(addition) reader processes per GPU; default: 3 (as the reference) up to 12 when the host has the cores')
     parser.add_argument('--max_epochs', dest='max_epochs', type=int, default=None, help='(addition) stop after this many epochs')
     a = parser.parse_args()
     print('Arguments:')
     for k, v in vars(a).items():
         print('{} = {}'.format(k, v))
     train_model(a.batch_size, a.test_every_n_steps, a.train_database_filepath, a.test_database_filepath, a.output_folder,
-                a.terminate_after_num_epochs_without_test_loss_improvement, a.learning_rate, bool(a.use_augmentation), a.max_epochs)
+                a.terminate_after_num_epochs_without_test_loss_improvement, a.learning_rate, bool(a.use_augmentation), a.max_epochs, a.reader_count)

@@ -116,26 +116,25 @@ def _loader_process(reader, worker_id):
 class Dataset:
     """What get_tf_dataset() hands out: an iterable of (image[C,H,W], label_1, label_2, label_3); ``batch(n)`` stacks
     n examples and moves them to the GPU, where the images are z-scored by the HIP kernel (the reference z-scores in
-    the reader processes on the CPU, imagereader.py:398)."""
+    the reader processes on the CPU, imagereader.py:398); ``prefetch(d)`` assembles up to d batches ahead in pinned host
+    memory on a background thread (tf.data's prefetch, train.py:61), so that taking examples off the worker queue and
+    stacking them overlaps the GPU step instead of preceding it."""
 
-    def __init__(self, reader, batch_size=None, device=None):
-        self.reader, self.batch_size, self.device = reader, batch_size, device
+    def __init__(self, reader, batch_size=None, device=None, prefetch_depth=0):
+        self.reader, self.batch_size, self.device, self.prefetch_depth = reader, batch_size, device, prefetch_depth
 
     def batch(self, n):
-        return Dataset(self.reader, int(n), self.device)
+        return Dataset(self.reader, int(n), self.device, self.prefetch_depth)
 
-    def prefetch(self, n):            # the bounded worker queue already prefetches (train.py:61)
-        return self
+    def prefetch(self, n):
+        return Dataset(self.reader, self.batch_size, self.device, max(1, min(int(n), 4)))     # batches, not examples: 4 is plenty
 
     def shard(self, num_shards, index):   # experimental_distribute_dataset: each replica reads its own examples
         return self
 
-    def __iter__(self):
+    def _examples(self):
+        """Lists of batch_size examples off the worker queue; a short tail is dropped like tf.data drop_remainder."""
         gen = self.reader.generator()
-        if self.batch_size is None:
-            yield from gen
-            return
-        dev = self.device or torch.device('cuda', torch.cuda.current_device())
         while True:
             ex = []
             for e in gen:
@@ -144,10 +143,65 @@ class Dataset:
                     break
             if len(ex) < self.batch_size:
                 return
-            imgs = torch.from_numpy(np.stack([e[0] for e in ex])).to(dev, non_blocking=True)
-            imgs = zscore_normalize_device(imgs)
-            labels = [torch.from_numpy(np.stack([e[i] for e in ex])).to(dev, non_blocking=True) for i in (1, 2, 3)]
-            yield (imgs, *labels)
+            yield ex
+
+    def __iter__(self):
+        if self.batch_size is None:
+            yield from self.reader.generator()
+            return
+        dev = self.device or torch.device('cuda', torch.cuda.current_device())
+        if not self.prefetch_depth:
+            for ex in self._examples():
+                imgs = torch.from_numpy(np.stack([e[0] for e in ex])).to(dev, non_blocking=True)
+                labels = [torch.from_numpy(np.stack([e[i] for e in ex])).to(dev, non_blocking=True) for i in (1, 2, 3)]
+                yield (zscore_normalize_device(imgs), *labels)
+            return
+        import queue
+        import threading
+        ready = queue.Queue(maxsize=self.prefetch_depth)
+        ring = [dict(bufs=None, event=None) for _ in range(self.prefetch_depth + 2)]
+        stop = threading.Event()
+
+        def hand_over(item):
+            while not stop.is_set():
+                try:
+                    ready.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def producer():
+            try:
+                for i, ex in enumerate(self._examples()):
+                    if stop.is_set():
+                        return
+                    slot = ring[i % len(ring)]
+                    if slot['event'] is not None:
+                        slot['event'].synchronize()          # the upload that last used these pinned buffers has finished
+                    if slot['bufs'] is None:
+                        slot['bufs'] = [torch.empty((len(ex),) + ex[0][j].shape, dtype=torch.from_numpy(ex[0][j]).dtype, pin_memory=True)
+                                        for j in range(4)]
+                    for j in range(4):
+                        np.stack([e[j] for e in ex], out=slot['bufs'][j].numpy())
+                    if not hand_over(slot):
+                        return
+            finally:
+                hand_over(None)
+
+        threading.Thread(target=producer, name='yolo3-prefetch', daemon=True).start()
+        try:
+            while True:
+                slot = ready.get()
+                if slot is None:
+                    return
+                dev_t = [b.to(dev, non_blocking=True) for b in slot['bufs']]
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                slot['event'] = ev
+                yield (zscore_normalize_device(dev_t[0]), dev_t[1], dev_t[2], dev_t[3])
+        finally:
+            stop.set()          # the consumer walked away (epoch boundary): the producer exits at its next hand-over
 
 
 class ImageReader:

@@ -760,7 +760,7 @@ class YoloV3:
         plan.run_decode(st)
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):      # the prefetch thread may allocate pinned memory meanwhile
             st = self._stream()
             plan.run_forward(st)
             plan.run_decode(st)
@@ -842,7 +842,7 @@ class YoloV3:
         self.moving.copy_(moving)
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):      # the prefetch thread may allocate pinned memory meanwhile
             st = self._stream()
             plan.run_forward(st)
             plan.run_loss(st)

@@ -4,6 +4,7 @@ tiled inference)."""
 import os
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -58,6 +59,34 @@ def test_device_tiler_matches_host_tiler(dtype):
             got = inference_tiled.tiles_to_device(img_dev, code, shape, table_dev, t0, cnt, tile).cpu().numpy()
             want = np.stack([t.astype(np.float32).transpose((2, 0, 1)) for t in tiles[t0:t0 + cnt]])
             assert np.array_equal(got, want), (shape, tile, t0)
+
+
+def test_dataset_prefetch_matches_plain_batches(tmp_path):
+    """Dataset.batch(n).prefetch(d) (background thread, pinned staging, GPU z-score) yields exactly what the plain batch
+    path yields: one in-order reader process, no shuffling; abandoning an iterator stops its producer thread."""
+    import threading
+    from test_cpu_dataplane import _make_db
+    from yolo3.imagereader import ImageReader
+    path, _ = _make_db(tmp_path, n=12, size=(64, 64, 3), seed=4)
+    anchors = [(64, 384), (384, 64)]
+    out = []
+    for depth in (0, 2):
+        rd = ImageReader(path, anchors, use_augmentation=False, shuffle=False, num_workers=1)
+        rd.startup()
+        ds = rd.get_tf_dataset().batch(4)
+        if depth:
+            ds = ds.prefetch(depth)
+        it = iter(ds)
+        out.append([[t.cpu().clone() for t in next(it)] for _ in range(3)])
+        del it
+        rd.shutdown()
+    for a, b in zip(*out):
+        assert len(a) == 4 and all(torch.equal(x, y) for x, y in zip(a, b))
+    assert out[0][0][0].shape == (4, 3, 64, 64) and out[0][0][0].is_floating_point()
+    deadline = time.time() + 5
+    while time.time() < deadline and any(t.name == 'yolo3-prefetch' and t.is_alive() for t in threading.enumerate()):
+        time.sleep(0.1)
+    assert not any(t.name == 'yolo3-prefetch' and t.is_alive() for t in threading.enumerate())
 
 
 def _write_dataset(tmp, n, size, K=2, seed=5):
