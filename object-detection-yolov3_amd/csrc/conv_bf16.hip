@@ -5,7 +5,7 @@
 //   A: activations NHWC bf16 (K = (tap, c) contiguous per pixel)
 //   B: kernels in the [tap][Cout][Cin] layout of the transposed-weight arena, converted to bf16 -- K-contiguous per
 //      output channel, so BOTH operands are "rows of 32 bf16 = 64 bytes" and share one loader and one LDS image:
-//      rows padded to 80 bytes, fragment = one conflict-free ds_read_b128 (8 bf16) at quad 2*kk + (lane >> 5).
+//      unpadded rows with XOR-swizzled 16-byte quads, fragment = one conflict-free ds_read_b128 (8 bf16).
 // Epilogue: + bias -> leaky-relu -> folded BatchNorm affine -> + residual (bf16) -> bf16 (or fp32 for the heads).
 // At 64 bytes of operands per 32 MFMA cycles this kernel is bound by the L2 -> LDS path, not by the matrix pipe.
 #include "common.h"
@@ -68,13 +68,19 @@ template <int BM, int BN, int WM, int WN, bool STAGED, int BK = 32>
 __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args p) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int Q = BK / 8;             // 16-byte quads per row and K step (BK = 32: 64-byte rows, 64: 128-byte rows)
-    constexpr int LDR = BK + 8;           // row pitch in u16 (+16 bytes: staggers the 16-byte fragment reads over the banks)
+    constexpr int LDR = BK;               // row pitch in u16: no padding -- the 16-byte quads of a row are XOR-swizzled instead:
+    // quad q of row r lives in slot q ^ f(r), f(r) = (r >> 2) & 3 for 64-byte rows, (r >> 1) & 7 for 128-byte rows.  A
+    // ds_write_b128 group (8 lanes) then covers whole rows = 32 distinct banks, and a ds_read_b128 group (16 lanes: same
+    // quad of 16 rows, MI355X_MICROARCH.md LDS table) hits 16 distinct 16-byte bank slots: both conflict free.
+    constexpr int SWZ_SHIFT = BK == 32 ? 2 : 1, SWZ_MASK = Q - 1;
     constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
     constexpr int A_LOADS = BM * Q / THREADS, B_LOADS = (BN * Q + THREADS - 1) / THREADS;
     static_assert(BM * Q % THREADS == 0 && TM % 32 == 0 && TN % 32 == 0 && (BK == 32 || BK == 64), "tile shape");
 
     // one LDS block: [2][BM] + [2][BN] operand rows in the main loop, re-used as the fp32 staging tile of the epilogue
-    __shared__ __attribute__((aligned(16))) u16 smem[2 * (BM + BN) * LDR];
+    constexpr int STAGE_U16 = (BM / WM) * (BN + 4) * 2;    // one wave-row band of the fp32 staging tile of the epilogue
+    constexpr int OPER_U16 = 2 * (BM + BN) * LDR;
+    __shared__ __attribute__((aligned(16))) u16 smem[OPER_U16 > STAGE_U16 ? OPER_U16 : STAGE_U16];
     u16(*As)[BM * LDR] = reinterpret_cast<u16(*)[BM * LDR]>(smem);
     u16(*Bs)[BN * LDR] = reinterpret_cast<u16(*)[BN * LDR]>(smem + 2 * BM * LDR);
 
@@ -144,11 +150,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
     auto lstore = [&](int buf, auto stage) {
         constexpr int S = decltype(stage)::value;
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) *reinterpret_cast<f32x4*>(&As[buf][((tid + i * THREADS) / Q) * LDR + quad * 8]) = ra[S][i];
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int row = (tid + i * THREADS) / Q;
+            *reinterpret_cast<f32x4*>(&As[buf][row * LDR + ((quad ^ ((row >> SWZ_SHIFT) & SWZ_MASK)) * 8)]) = ra[S][i];
+        }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const int idx = tid + i * THREADS;
-            if (BN * Q % THREADS == 0 || idx < BN * Q) *reinterpret_cast<f32x4*>(&Bs[buf][(idx / Q) * LDR + quad * 8]) = rb[S][i];
+            const int row = idx / Q;
+            if (BN * Q % THREADS == 0 || idx < BN * Q)
+                *reinterpret_cast<f32x4*>(&Bs[buf][row * LDR + ((quad ^ ((row >> SWZ_SHIFT) & SWZ_MASK)) * 8)]) = rb[S][i];
         }
     };
     using S0 = std::integral_constant<int, 0>;
@@ -164,15 +175,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
 
     const int nk = p.K / BK;
     auto compute = [&](int cur) {
-        const u16* as = &As[cur][(wm * TM + l31) * LDR + lh * 8];
-        const u16* bs = &Bs[cur][(wn * TN + l31) * LDR + lh * 8];
+        const u16* as = &As[cur][(wm * TM + l31) * LDR];
+        const u16* bs = &Bs[cur][(wn * TN + l31) * LDR];
+        const int swz = (l31 >> SWZ_SHIFT) & SWZ_MASK;      // rows advance in multiples of 32 per fragment: f(row) = f(l31)
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             bf16x8 av[MB], bv[NB];
+            const int qo = ((2 * kk + lh) ^ swz) * 8;
 #pragma unroll
-            for (int i = 0; i < MB; ++i) av[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * LDR + kk * 16);
+            for (int i = 0; i < MB; ++i) av[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * LDR + qo);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * LDR + kk * 16);
+            for (int j = 0; j < NB; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * LDR + qo);
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
