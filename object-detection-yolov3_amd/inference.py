@@ -27,7 +27,7 @@ def inference(image_folder, image_format, saved_model_filepath, output_folder, m
     # replicas only (no collective): under `python -m torch.distributed.run --nproc-per-node N` every rank takes every N-th image
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
     if world > 1:
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
         img_filepath_list = sorted(img_filepath_list)[rank::world]
     yolo = load_model(saved_model_filepath)
     yolo.inference_precision = precision          # 'bf16': bf16 MFMA convs, fp32 heads / decode / NMS (not in the reference)

@@ -182,7 +182,7 @@ def inference_image_folder(image_folder, image_format, saved_model_filepath, out
     # replicas only (no collective): under `python -m torch.distributed.run --nproc-per-node N` every rank takes every N-th image
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
     if world > 1:
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
         img_filepath_list = sorted(img_filepath_list)[rank::world]
     path = os.path.join(saved_model_filepath, 'yolov3.npz') if os.path.isdir(saved_model_filepath) else saved_model_filepath
     yolo = YoloV3.from_file(path)

@@ -142,6 +142,15 @@ def test_cli_train_then_inference(tmp_path):
             x, y, w, h, c = (int(v) for v in ln.split(','))
             assert 0 <= x <= 256 and 0 <= y <= 256 and w > 8 and h > 8 and c in (0, 1)
 
+    # the same folder under a two-rank launcher (replicas only: every rank takes every second image, bf16 conv path)
+    det2 = os.path.join(tmp, 'dets2')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29533', os.path.join(PKG, 'inference.py'), '--saved-model-filepath', os.path.join(out, 'saved_model'),
+                        '--output-folder', det2, '--image-folder', img_dir, '--image-format', 'png', '--min-box-size', '8', '--precision', 'bf16'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert sorted(os.listdir(det2)) == ['a0.csv', 'a1.csv'] and r.stdout.count('Found:') == 2
+
     # inference_tiled.py on a larger image, tile = training size
     big_dir, big_out = os.path.join(tmp, 'big'), os.path.join(tmp, 'bigdets')
     os.makedirs(big_dir)
