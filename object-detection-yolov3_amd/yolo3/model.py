@@ -12,6 +12,7 @@ HIP graph).  torch is used for device memory, streams and the RCCL all-reduce
 only; there is no torch.nn / autograd / CPU fallback on this path.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -414,6 +415,17 @@ class _Plan:
         self.wg_ws_bytes = wg_need
 
         first_src = self.x0
+        # The kernel gradient of a layer and its data gradient both start from dz and are independent.  Each is a single
+        # round of workgroups with ~8 us of prologue + epilogue in which the matrix pipe idles, so the kernel gradients go to
+        # a second stream and fill those bubbles: 23.3 -> 21.4 ms per step with host launches.  (Replayed as a HIP graph
+        # the two branches gained nothing -- 23.8 ms -- so a graph-captured step keeps one stream.)  dz is double-buffered:
+        # bn_bwd_apply of layer i-2 waits for the kernel gradient of layer i that still reads the buffer.
+        two = (not mdl.use_graph) and os.environ.get('Y3_WGRAD_STREAM', '1') != '0'
+        self.side = torch.cuda.Stream(device=mdl.device) if two else None
+        self.events = []
+        dz_bufs = [self.dz, torch.empty_like(self.dz)] if two else [self.dz]
+        dz_busy = [None, None]          # event index of the wgrad still reading each dz buffer
+        nconv = 0
         for op in reversed(self.ops):
             kind = op[0]
             if kind == 'head':
@@ -442,26 +454,65 @@ class _Plan:
                     dr = self._grad_of(resid)
                     self._emit(self.bwd, lib.y3_add_inplace if resid.gw else lib.y3_copy, dy.v, dr.v)
                     resid.mark_written()
-                dz = _T(self.dz, a.n, a.h, a.w, sp.cout)
+                slot = nconv % len(dz_bufs)
+                nconv += 1
+                dz = _T(dz_bufs[slot], a.n, a.h, a.w, sp.cout)
+                self.keep.append(dz)
                 self._emit(self.bwd, lib.y3_bn_bwd_reduce, dy.v, a.v, smean, srstd, LRELU_ALPHA, self.bnb_ws.data_ptr(), None)
                 self._emit(self.bwd, lib.y3_bn_bwd_finalize, self.bnb_ws.data_ptr(), lib.y3_bn_bwd_partials(a.m, sp.cout), sp.cout, a.m,
                            mdl.params.data_ptr() + 4 * sp.g_off, smean, srstd, LRELU_ALPHA, gptr(sp.g_off), gptr(sp.be_off), gptr(sp.b_off), coef)
+                if two and dz_busy[slot] is not None:
+                    self.bwd.append(('main_wait', dz_busy[slot]))
                 self._emit(self.bwd, lib.y3_bn_bwd_apply, dy.v, a.v, coef, LRELU_ALPHA, dz.v)
-                self._emit(self.bwd, lib.y3_conv2d_wgrad, src.v, dz.v, sp.k, sp.s, gptr(sp.w_off), self.wg_ws.data_ptr(), self.wg_ws_bytes)
+                if two:
+                    self.events += [torch.cuda.Event(), torch.cuda.Event()]
+                    e_dz, e_wg = len(self.events) - 2, len(self.events) - 1
+                    self.bwd.append(('record', e_dz))
+                    wargs = (src.v, dz.v, sp.k, sp.s, gptr(sp.w_off), self.wg_ws.data_ptr(), self.wg_ws_bytes)
+                    self.keep.append(wargs)
+                    self.bwd.append(('side_call', (lib.y3_conv2d_wgrad, wargs, e_dz, e_wg)))
+                    dz_busy[slot] = e_wg
+                else:
+                    self._emit(self.bwd, lib.y3_conv2d_wgrad, src.v, dz.v, sp.k, sp.s, gptr(sp.w_off), self.wg_ws.data_ptr(), self.wg_ws_bytes)
                 if src is not first_src:
                     ds = self._grad_of(src)
                     self._conv_call(self.bwd, ds.m, sp, lib.y3_conv2d_dgrad, dz.v, Wt.data_ptr() + 4 * sp.w_off, sp.k, sp.s, ds.v,
                                     EPI_ACCUM if src.gw else 0, need=int(lib.y3_conv2d_dgrad_workspace(dz.v, sp.k, sp.s, ds.v)))
                     src.mark_written()
                 self.bwd.append(('layer_done', i))
+        for e in dz_busy:
+            if two and e is not None:
+                self.bwd.append(('main_wait', e))
 
     # -- execution -------------------------------------------------------------------
-    @staticmethod
-    def _run(lst, stream, hook=None):
+    def _run(self, lst, stream, hook=None):
+        main = None
+        pending = []                   # kernel gradients in flight on the side stream (event indices)
         for fn, args in lst:
             if fn == 'layer_done':
                 if hook is not None:
+                    dist_ = self.model.dist
+                    if pending and (dist_ is None or args in getattr(dist_, '_by_layer', {args: 1})):
+                        for e in pending:          # a gradient bucket is about to be all-reduced: its kernel gradients must be in
+                            main.wait_event(self.events[e])
+                        pending = []
                     hook(args)
+                continue
+            if fn in ('record', 'main_wait', 'side_call'):
+                if main is None:
+                    main = torch.cuda.current_stream(self.model.device)
+                if fn == 'record':
+                    self.events[args].record(main)
+                elif fn == 'main_wait':
+                    main.wait_event(self.events[args])
+                else:
+                    f2, a2, e_wait, e_done = args
+                    self.side.wait_event(self.events[e_wait])
+                    rc = f2(*a2, self.side.cuda_stream)
+                    if rc != 0:
+                        check(rc, f2.__name__)
+                    self.events[e_done].record(self.side)
+                    pending.append(e_done)
                 continue
             rc = fn(*args, stream)
             if rc != 0:

@@ -28,8 +28,10 @@ for rep in range(3):
             plan.run_loss(st)
             continue
         for fn, args in lst:
-            if fn == 'layer_done':
+            if fn in ('layer_done', 'record', 'main_wait'):
                 continue
+            if fn == 'side_call':              # per-launch timing in isolation: everything on one stream here
+                fn, args = args[0], args[1]
             nm = names.get(getattr(fn, '__name__', ''))
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
