@@ -35,7 +35,7 @@ reader.startup()                          # worker processes are forked before t
 import torch                              # noqa: E402
 from yolo3.model import YoloV3            # noqa: E402
 ds = reader.get_tf_dataset().batch(8).prefetch(workers)
-yolo = YoloV3(8, reader.get_image_size(), reader.get_number_classes(), anchors, 1e-4, use_graph=True)
+yolo = YoloV3(8, reader.get_image_size(), reader.get_number_classes(), anchors, 1e-4)
 it = iter(ds)
 t_data = t_step = 0.0
 n = 0
