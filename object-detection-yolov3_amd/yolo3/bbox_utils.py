@@ -23,6 +23,7 @@ class _NmsBuffers:
 
 
 _cache = {}
+_copy_streams = {}
 
 
 def nms_device(rows, min_box_size=0.0, iou_threshold=0.3, score_threshold=0.1, clip_wh=None, private_outputs=False):
@@ -34,7 +35,8 @@ def nms_device(rows, min_box_size=0.0, iou_threshold=0.3, score_threshold=0.1, c
     rows = rows.contiguous()
     n, nb, d = rows.shape
     k = d - 5
-    key = (n, nb, k, str(rows.device))
+    st_obj = torch.cuda.current_stream(rows.device)
+    key = (n, nb, k, str(rows.device), st_obj.cuda_stream)       # one workspace per stream: launches on a stream run in order
     buf = _cache.get(key)
     if buf is None:
         buf = _cache[key] = _NmsBuffers(n, nb, k, rows.device)
@@ -43,10 +45,9 @@ def nms_device(rows, min_box_size=0.0, iou_threshold=0.3, score_threshold=0.1, c
     else:
         keep_idx, keep_cnt, keep_score = buf.keep_idx, buf.keep_cnt, buf.keep_score
     cw, chh = (float(clip_wh[0]), float(clip_wh[1])) if clip_wh is not None else (-1.0, -1.0)
-    st = torch.cuda.current_stream(rows.device).cuda_stream
     check(lib.y3_nms_per_class(rows.data_ptr(), n, nb, k, float(min_box_size), float(score_threshold), float(iou_threshold), cw, chh,
                                keep_idx.data_ptr(), keep_cnt.data_ptr(), keep_score.data_ptr(), nb, buf.ws.data_ptr(),
-                               buf.ws_bytes, st), 'y3_nms_per_class')
+                               buf.ws_bytes, st_obj.cuda_stream), 'y3_nms_per_class')
     return keep_idx, keep_cnt, keep_score
 
 
@@ -57,8 +58,20 @@ def detect_async(rows, min_box_size, iou_threshold=0.3, score_threshold=0.1, cli
     keep_idx, keep_cnt, keep_score = nms_device(rows, min_box_size, iou_threshold, score_threshold, clip_wh, private_outputs=True)
     n, nb, d = rows.shape
     k = d - 5
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream(rows.device))
 
     def collect():
+        # the copies run on a stream of their own behind the NMS's event: queued on the NMS's stream they would also
+        # wait for whatever the caller has put on it since (the next batches of a tiled image)
+        cs = _copy_streams.get(str(rows.device))
+        if cs is None:
+            cs = _copy_streams[str(rows.device)] = torch.cuda.Stream(device=rows.device)
+        cs.wait_event(done)
+        with torch.cuda.stream(cs):
+            return _collect()
+
+    def _collect():
         cnt = keep_cnt.cpu().numpy()                       # the only synchronisation point besides the final copies
         out = [(None, None, None, None)] * n
         total = int(cnt.sum())

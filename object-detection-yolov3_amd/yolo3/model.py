@@ -542,10 +542,12 @@ class _CallableModel:
         self._y = yolo
         self._fm = feature_maps
 
-    def __call__(self, batch, training=False):
+    supports_slots = True      # __call__(..., slot=k): k-th independent set of activation buffers (concurrent streams)
+
+    def __call__(self, batch, training=False, slot=0):
         if self._fm:
             return self._y.feature_maps(batch, training=training)
-        return self._y.predict(batch)
+        return self._y.predict(batch, slot=slot)
 
     @property
     def trainable_weights(self):
@@ -750,6 +752,7 @@ class YoloV3:
             self.params_t_bf16 = torch.zeros(self.arena_floats, dtype=torch.bfloat16, device=self.device)
         if self._bf16_stale:
             check(lib.y3_f32_to_bf16(self.params_t.data_ptr(), self.params_t_bf16.data_ptr(), self.arena_floats, self._stream()), 'y3_f32_to_bf16')
+            torch.cuda.current_stream(self.device).synchronize()     # rare (weights changed); other streams may read the copy next
             self._bf16_stale = False
 
     # ---- reference API (model.py:466-479) ---------------------------------------------
@@ -769,9 +772,9 @@ class YoloV3:
         return self.learning_rate
 
     # ---- execution -------------------------------------------------------------------------
-    def _plan(self, n, training, bf16=False):
+    def _plan(self, n, training, bf16=False, slot=0):
         bf16 = bool(bf16) and not training
-        key = (int(n), bool(training), bf16)
+        key = (int(n), bool(training), bf16, int(slot))
         if bf16:
             self._refresh_bf16()
         if key not in self._plans:
@@ -788,11 +791,13 @@ class YoloV3:
             for dst, src in zip(plan.gt, gt_data):
                 dst.copy_(torch.as_tensor(src).to(torch.float32).reshape(dst.shape), non_blocking=True)
 
-    def predict(self, images, precision=None):
+    def predict(self, images, precision=None, slot=0):
         """The saved 'yolov3' model (model.py:463): NCHW in -> [N, Nb, 5+K].  precision 'bf16' runs every conv after
-        the RGB layer on the bf16 MFMA path (fp32 accumulate, fp32 heads / decode); default self.inference_precision."""
+        the RGB layer on the bf16 MFMA path (fp32 accumulate, fp32 heads / decode); default self.inference_precision.
+        Calls with different ``slot`` use separate activation / output buffers and may run concurrently on different
+        streams (inference_tiled does that); calls with the same slot must be stream-ordered."""
         n = int(images.shape[0])
-        plan = self._plan(n, False, (precision or self.inference_precision) == 'bf16')
+        plan = self._plan(n, False, (precision or self.inference_precision) == 'bf16', slot)
         self._load_inputs(plan, images)
         if self.use_graph:
             if plan.infer_graph is None:
