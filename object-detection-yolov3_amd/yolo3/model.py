@@ -425,6 +425,7 @@ class _Plan:
         self.events = []
         dz_bufs = [self.dz, torch.empty_like(self.dz)] if two else [self.dz]
         dz_busy = [None, None]          # event index of the wgrad still reading each dz buffer
+        head_wg = []
         nconv = 0
         for op in reversed(self.ops):
             kind = op[0]
@@ -433,7 +434,16 @@ class _Plan:
                 sp = specs[i]
                 dfm = fm.grad
                 self._emit(self.bwd, lib.y3_colsum, dfm.v, gptr(sp.b_off))
-                self._emit(self.bwd, lib.y3_conv2d_wgrad, src.v, dfm.v, 1, 1, gptr(sp.w_off), self.wg_ws.data_ptr(), self.wg_ws_bytes)
+                if two:     # every kernel gradient goes through the side stream: they share one slab workspace, in stream order
+                    self.events += [torch.cuda.Event(), torch.cuda.Event()]
+                    e_go, e_wg = len(self.events) - 2, len(self.events) - 1
+                    self.bwd.append(('record', e_go))
+                    wargs = (src.v, dfm.v, 1, 1, gptr(sp.w_off), self.wg_ws.data_ptr(), self.wg_ws_bytes)
+                    self.keep.append(wargs)
+                    self.bwd.append(('side_call', (lib.y3_conv2d_wgrad, wargs, e_go, e_wg)))
+                    head_wg.append(e_wg)
+                else:
+                    self._emit(self.bwd, lib.y3_conv2d_wgrad, src.v, dfm.v, 1, 1, gptr(sp.w_off), self.wg_ws.data_ptr(), self.wg_ws_bytes)
                 ds = self._grad_of(src)
                 self._conv_call(self.bwd, ds.m, sp, lib.y3_conv2d_dgrad, dfm.v, Wt.data_ptr() + 4 * sp.w_off, 1, 1, ds.v, EPI_ACCUM if src.gw else 0,
                                 need=int(lib.y3_conv2d_dgrad_workspace(dfm.v, 1, 1, ds.v)))
@@ -480,7 +490,7 @@ class _Plan:
                                     EPI_ACCUM if src.gw else 0, need=int(lib.y3_conv2d_dgrad_workspace(dz.v, sp.k, sp.s, ds.v)))
                     src.mark_written()
                 self.bwd.append(('layer_done', i))
-        for e in dz_busy:
+        for e in dz_busy + head_wg[-1:]:
             if two and e is not None:
                 self.bwd.append(('main_wait', e))
 
