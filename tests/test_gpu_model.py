@@ -229,9 +229,16 @@ def test_test_step_and_graph_replay():
     b = YoloV3(n, [img, img, 3], K, ANCHORS, learning_rate=1e-3, use_graph=True)
     a.set_weights(params)
     b.set_weights(params)
-    la = [float(a.train_step((images.cuda(), gt_dev))) for _ in range(3)]
-    lb = [float(b.train_step((images.cuda(), gt_dev))) for _ in range(3)]
-    np.testing.assert_allclose(la, lb, rtol=1e-5)
+    # a launches from the host with the kernel gradients on a second stream, b replays a single-stream graph: the kernels
+    # and their accumulation orders are the same, so gradients and weights must agree BIT FOR BIT -- any hazard between
+    # the two streams (a shared workspace, a buffer reused too early) shows up here
+    la, lb = [], []
+    for _ in range(4):
+        la.append(float(a.train_step((images.cuda(), gt_dev))))
+        lb.append(float(b.train_step((images.cuda(), gt_dev))))
+        torch.cuda.synchronize()
+        assert torch.equal(a.grads, b.grads) and torch.equal(a.params, b.params) and torch.equal(a.moving, b.moving)
+    np.testing.assert_allclose(la, lb, rtol=0)
     for wa, wb in zip(a.trainable_weights(), b.trainable_weights()):
         np.testing.assert_allclose(wa, wb, rtol=0, atol=2.1e-3)
     # inference graphs (fp32 and bf16 plans) replay to the eager rows, before and after the weights move again
