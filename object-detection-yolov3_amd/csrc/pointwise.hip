@@ -205,9 +205,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > npix) r1 = npix;
-    for (long long r = r0 + rg; r < r1; r += rpp) {
-        const float4 d4 = *reinterpret_cast<const float4*>(dy + r * dy_ld + c);
-        const float4 a4 = *reinterpret_cast<const float4*>(a + r * a_ld + c);
+    auto accumulate = [&](const float4 d4, const float4 a4) {
         const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -220,7 +218,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             acc[3][e] += s;
             acc[4][e] += xh * s;
         }
+    };
+    // four rows per trip: eight 16-byte loads in flight per thread (the kernel runs at 2 waves / SIMD); rows are still
+    // accumulated in their original order
+    long long r = r0 + rg;
+    for (; r + 3LL * rpp < r1; r += 4LL * rpp) {
+        float4 d4[4], a4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            d4[u] = *reinterpret_cast<const float4*>(dy + (r + (long long)u * rpp) * dy_ld + c);
+            a4[u] = *reinterpret_cast<const float4*>(a + (r + (long long)u * rpp) * a_ld + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) accumulate(d4[u], a4[u]);
     }
+    for (; r < r1; r += rpp)
+        accumulate(*reinterpret_cast<const float4*>(dy + r * dy_ld + c), *reinterpret_cast<const float4*>(a + r * a_ld + c));
 #pragma unroll
     for (int j = 0; j < 5; ++j)
 #pragma unroll
