@@ -8,6 +8,7 @@ fp32, synthetic N(0,1) images / random labels / Glorot weights, all resident
 in HBM before the timed region.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          # spawns its own N ranks (fresh processes, before any GPU call)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -194,6 +195,30 @@ def cpu_baseline(seed, budget_s=25.0):
                        '%d step(s) at batch %d, 416x416, %.1f s' % (steps, bs, t))
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start N fresh rank processes of this script (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set) and relay rank 0's JSON line.
+    This process has not touched the GPU (importing torch does not initialise HIP) and never does: it only waits."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out0 = procs[0].communicate()[0]
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit('rank exit codes %s' % codes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -212,9 +237,14 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        return spawn_ranks(args.gpus)              # plain `python bench.py --gpus N`: be our own launcher
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
-    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+        raise SystemExit('--gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
+    ndev = torch.cuda.device_count()               # counting devices does not initialise the GPU
+    if world > 1 and args.backend == 'nccl' and ndev < int(os.environ.get('LOCAL_WORLD_SIZE', str(world))):
+        raise SystemExit('backend nccl (= RCCL) needs one GPU per rank: %d visible, %d ranks (use --backend gloo to rehearse on fewer GPUs)' % (ndev, world))
+    torch.cuda.set_device(local_rank % max(1, ndev))
     import torch.distributed as dist
     from yolo3.model import YoloV3
     strategy = None

@@ -14,15 +14,24 @@ from yolo3 import bbox_utils, imagereader, lmdbio
 from yolo3.isg_ai_pb import ImageYoloBoxesPair
 
 
-def make_record(img, boxes, txn_nb, name):
-    """(key bytes, value bytes) of one example (build_lmdb.py:46-69, 88-96)."""
+def record_key(boxes, txn_nb, name):
+    """"<n>_<name>:<sorted unique class ids>" (build_lmdb.py:88-96)."""
+    boxes = np.asarray(boxes, dtype=np.int32).reshape(-1, 5)
+    present = np.unique(boxes[:, 4]).astype(np.int32)
+    return '{}_{}:{}'.format(txn_nb, name, ','.join(str(k) for k in present)).encode('ascii')
+
+
+def encode_record(img, boxes):
+    """Serialised isg_ai.ImageYoloBoxesPair of one example (build_lmdb.py:46-69)."""
     img = np.asarray(img, dtype=np.uint8)
     if img.ndim == 2:
         img = img[:, :, None]
-    boxes = np.asarray(boxes, dtype=np.int32).reshape(-1, 5)
-    present = np.unique(boxes[:, 4]).astype(np.int32)
-    key = '{}_{}:{}'.format(txn_nb, name, ','.join(str(k) for k in present))
-    return key.encode('ascii'), ImageYoloBoxesPair.from_arrays(img, boxes).SerializeToString()
+    return ImageYoloBoxesPair.from_arrays(img, np.asarray(boxes, dtype=np.int32).reshape(-1, 5)).SerializeToString()
+
+
+def make_record(img, boxes, txn_nb, name):
+    """(key bytes, value bytes) of one example."""
+    return record_key(boxes, txn_nb, name), encode_record(img, boxes)
 
 
 def generate_database(csv_files, img_files, output_folder, database_name):
@@ -31,11 +40,19 @@ def generate_database(csv_files, img_files, output_folder, database_name):
     if os.path.exists(out):
         print('Deleting existing database')
         shutil.rmtree(out)
-    items = []
+    # keys need the boxes only (cheap); images are read, serialised and written one at a time in key order
+    # (the reference commits every 1000 records, build_lmdb.py:97-100 -- the dataset never sits in memory)
+    source = {}
     for n, (img_fp, csv_fp) in enumerate(zip(img_files, csv_files)):
         name, _ = os.path.splitext(os.path.basename(csv_fp))
-        items.append(make_record(imagereader.imread(img_fp), bbox_utils.load_boxes_to_xywhc(csv_fp), n, name))
-    lmdbio.write_environment(out, items)
+        boxes = bbox_utils.load_boxes_to_xywhc(csv_fp)
+        source[record_key(boxes, n, name)] = (img_fp, boxes)
+
+    def value_of(key):
+        img_fp, boxes = source[key]
+        return encode_record(imagereader.imread(img_fp), boxes)
+
+    lmdbio.write_environment_stream(out, sorted(source), value_of)
     with open(os.path.join(out, 'annotation_list.csv'), 'w') as fh:
         for csv_fp in csv_files:
             fh.write('{}\n'.format(os.path.splitext(os.path.basename(csv_fp))[0]))

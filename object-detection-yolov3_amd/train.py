@@ -20,10 +20,34 @@ import time
 import numpy as np
 
 READER_COUNT = 3  # per gpu (train.py:16)
+CONVERGENCE_TOLERANCE = 1e-4  # train.py:185
+
+
+def best_epoch_of(test_loss, tolerance=CONVERGENCE_TOLERANCE):
+    """train.py:185-192: the FIRST epoch whose test loss is within `tolerance` of the minimum."""
+    error_from_best = np.abs(np.asarray(test_loss) - np.min(test_loss))
+    error_from_best[error_from_best < tolerance] = 0
+    return int(np.where(error_from_best == 0)[0][0])
+
+
+def should_stop(test_loss, early_stopping_count, tolerance=CONVERGENCE_TOLERANCE):
+    """train.py:193-197: stop once more than `early_stopping_count` epochs have passed since the best one."""
+    return len(test_loss) - best_epoch_of(test_loss, tolerance) > early_stopping_count
+
+
+def is_new_minimum(test_loss):
+    """train.py:178: checkpoint when the newest test loss is the (first) minimum of the series."""
+    return (len(test_loss) - 1) == int(np.argmin(test_loss))
+
+
+def abort_on_nan(loss_value, message):
+    """train.py:124-125,151-152."""
+    if np.isnan(float(loss_value)):
+        raise RuntimeError(message)
 
 
 def train_model(batch_size, test_every_n_steps, train_database_filepath, test_database_filepath, output_folder, early_stopping_count,
-                learning_rate, use_augmentation, max_epochs=None, reader_count=None):
+                learning_rate, use_augmentation, max_epochs=None, reader_count=None, backend='nccl'):
     os.makedirs(output_folder, exist_ok=True)
     anchors = [(64, 384), (384, 64)]
 
@@ -40,7 +64,10 @@ def train_model(batch_size, test_every_n_steps, train_database_filepath, test_da
     # readers first: their worker processes are forked before this process touches the GPU
     from yolo3 import imagereader
     print('Setting up test image reader')
-    test_reader = imagereader.ImageReader(test_database_filepath, anchors, use_augmentation=False, shuffle=False, num_workers=reader_count)
+    # one reader per rank: the unshuffled test reader takes this rank's stride of the key list (the reference splits one
+    # global test batch over its replicas, train.py:64-66)
+    test_reader = imagereader.ImageReader(test_database_filepath, anchors, use_augmentation=False, shuffle=False, num_workers=reader_count,
+                                          num_shards=world, shard_index=rank)
     print('Test Reader has {} images'.format(test_reader.get_image_count()))
     print('Setting up training image reader')
     train_reader = imagereader.ImageReader(train_database_filepath, anchors, use_augmentation=use_augmentation, shuffle=True,
@@ -55,11 +82,16 @@ def train_model(batch_size, test_every_n_steps, train_database_filepath, test_da
         import torch
         import torch.distributed as dist
         from yolo3 import model
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
         strategy = None
         if world > 1:
             os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            if backend == 'nccl':                  # = RCCL over xGMI, one GPU per rank
+                if torch.cuda.device_count() < int(os.environ.get('LOCAL_WORLD_SIZE', str(world))):
+                    raise RuntimeError('backend nccl (RCCL) needs one GPU per rank; use --backend gloo to rehearse on fewer')
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            else:
+                dist.init_process_group(backend)
             from yolo3.parallel import DataParallel
             strategy = DataParallel()
 
@@ -112,8 +144,7 @@ def train_model(batch_size, test_every_n_steps, train_database_filepath, test_da
                     break
                 inputs = (batch_images, (l1, l2, l3), *train_metrics)
                 loss_value = yolo.dist_train_step(strategy, inputs)
-                if np.isnan(float(loss_value)):
-                    raise RuntimeError('Training Loss went to NaN, try a lower learning rate')
+                abort_on_nan(loss_value, 'Training Loss went to NaN, try a lower learning rate')
                 print('Train Epoch {}: Batch {}/{}: Loss {}'.format(epoch, step, train_epoch_size, train_metrics[0].result()))
                 log_scalars('train', int(epoch * train_epoch_size + step), train_metrics)
                 for m in train_metrics:
@@ -125,8 +156,7 @@ def train_model(batch_size, test_every_n_steps, train_database_filepath, test_da
                     break
                 inputs = (batch_images, (l1, l2, l3), *test_metrics)
                 loss_value = yolo.dist_test_step(strategy, inputs)
-                if np.isnan(float(loss_value)):
-                    raise RuntimeError('Test Loss went to NaN')
+                abort_on_nan(loss_value, 'Test Loss went to NaN')
                 epoch_test_loss.append(float(loss_value))
             test_loss.append(np.mean(epoch_test_loss))
             print('Test Epoch: {}: Loss = {}'.format(epoch, test_metrics[0].result()))
@@ -141,24 +171,21 @@ def train_model(batch_size, test_every_n_steps, train_database_filepath, test_da
                         csvfile.write('\n')
             print('Epoch took: {} s'.format(time.time() - start_time))
 
-            if (len(test_loss) - 1) == np.argmin(test_loss):
+            if is_new_minimum(test_loss):
                 print('Test loss improved: {}, saving checkpoint'.format(np.min(test_loss)))
-                if strategy is not None:
-                    strategy.mean_moving_stats(yolo.moving)       # sync-on-read MEAN of the BN moving stats (App. C4)
+                # BN moving statistics are sync-on-read: the checkpoint stores their MEAN over the replicas (App. C4); every
+                # replica keeps its own running values (a collective: all ranks take part, rank 0 writes)
+                saved_moving = strategy.mean_moving_stats(yolo.moving) if strategy is not None else None
                 training_checkpoint_filepath = os.path.join(output_folder, 'checkpoint', 'ckpt.npz')
                 if rank == 0:
                     os.makedirs(os.path.dirname(training_checkpoint_filepath), exist_ok=True)
-                    yolo.save_weights(training_checkpoint_filepath)
+                    yolo.save_weights(training_checkpoint_filepath, moving=saved_moving)
 
-            CONVERGENCE_TOLERANCE = 1e-4
             print('Best Current Epoch Selection:')
             print('Test Loss:')
             print(test_loss)
-            error_from_best = np.abs(np.asarray(test_loss) - np.min(test_loss))
-            error_from_best[error_from_best < CONVERGENCE_TOLERANCE] = 0
-            best_epoch = np.where(error_from_best == 0)[0][0]
-            print('Best epoch: {}'.format(best_epoch))
-            if len(test_loss) - best_epoch > early_stopping_count:
+            print('Best epoch: {}'.format(best_epoch_of(test_loss)))
+            if should_stop(test_loss, early_stopping_count):
                 break
             epoch = epoch + 1
             if max_epochs is not None and epoch >= max_epochs:
@@ -194,9 +221,10 @@ if __name__ == "__main__":
     parser.add_argument('--use_augmentation', dest='use_augmentation', type=int, default=1)
     parser.add_argument('--reader_count', dest='reader_count', type=int, default=None, help='(addition) reader processes per GPU; default: 3 (as the reference) up to 12 when the host has the cores')
     parser.add_argument('--max_epochs', dest='max_epochs', type=int, default=None, help='(addition) stop after this many epochs')
+    parser.add_argument('--backend', dest='backend', type=str, default='nccl', help='(addition) torch.distributed backend under torch.distributed.run: nccl (= RCCL, one GPU per rank) or gloo (rehearsal; ranks may share a GPU)')
     a = parser.parse_args()
     print('Arguments:')
     for k, v in vars(a).items():
         print('{} = {}'.format(k, v))
     train_model(a.batch_size, a.test_every_n_steps, a.train_database_filepath, a.test_database_filepath, a.output_folder,
-                a.terminate_after_num_epochs_without_test_loss_improvement, a.learning_rate, bool(a.use_augmentation), a.max_epochs, a.reader_count)
+                a.terminate_after_num_epochs_without_test_loss_improvement, a.learning_rate, bool(a.use_augmentation), a.max_epochs, a.reader_count, a.backend)

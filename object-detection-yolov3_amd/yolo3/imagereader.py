@@ -129,12 +129,16 @@ class Dataset:
     def prefetch(self, n):
         return Dataset(self.reader, self.batch_size, self.device, max(1, min(int(n), 4)))     # batches, not examples: 4 is plenty
 
-    def shard(self, num_shards, index):   # experimental_distribute_dataset: each replica reads its own examples
+    def shard(self, num_shards, index):
+        """experimental_distribute_dataset (train.py:62,66): every replica reads its own examples.  The reader's
+        workers are forked at startup(), so the shard must be fixed before that (ImageReader(..., num_shards, shard_index));
+        on a started reader this only checks that the request matches."""
+        self.reader.set_shard(num_shards, index)
         return self
 
     def _examples(self):
         """Lists of batch_size examples off the worker queue; a short tail is dropped like tf.data drop_remainder."""
-        gen = self.reader.generator()
+        gen = self.reader.raw_generator()
         while True:
             ex = []
             for e in gen:
@@ -147,7 +151,7 @@ class Dataset:
 
     def __iter__(self):
         if self.batch_size is None:
-            yield from self.reader.generator()
+            yield from self.reader.generator()           # z-scored examples, as the reference's unbatched dataset yields them
             return
         dev = self.device or torch.device('cuda', torch.cuda.current_device())
         if not self.prefetch_depth:
@@ -208,7 +212,12 @@ class ImageReader:
     """imagereader.ImageReader (imagereader.py:79-460): same constructor, startup / shutdown / get_image_size /
     get_number_classes / get_image_count / get_example / generator; get_tf_dataset() returns a ``Dataset``."""
 
-    def __init__(self, img_db, anchors, use_augmentation=True, balance_classes=False, shuffle=True, num_workers=1):
+    def __init__(self, img_db, anchors, use_augmentation=True, balance_classes=False, shuffle=True, num_workers=1, num_shards=1, shard_index=0):
+        """num_shards / shard_index (addition): with one process per GPU every rank owns a reader; an unshuffled reader
+        (the test set) then serves every num_shards-th stride of the key list, so the ranks evaluate disjoint images like
+        the replicas of the reference's one distributed test batch."""
+        self.num_shards, self.shard_index = int(num_shards), int(shard_index)
+        assert 0 <= self.shard_index < self.num_shards
         self.image_db = img_db
         self.use_augmentation = use_augmentation
         self.queue_starvation = False
@@ -266,6 +275,15 @@ class ImageReader:
     def get_image_count(self):
         return int(len(self.keys_flat))
 
+    def set_shard(self, num_shards, index):
+        if self.workers:
+            if (int(num_shards), int(index)) != (self.num_shards, self.shard_index):
+                raise RuntimeError('reader already started as shard {}/{}; pass num_shards / shard_index to ImageReader()'.format(
+                    self.shard_index, self.num_shards))
+            return
+        assert 0 <= int(index) < int(num_shards)
+        self.num_shards, self.shard_index = int(num_shards), int(index)
+
     def startup(self):
         self.done = False
         self.workers = [self._ctx.Process(target=_loader_process, args=(self, i), daemon=True) for i in range(self.nb_workers)]
@@ -301,9 +319,11 @@ class ImageReader:
             return self.keys_flat[random.randint(0, len(self.keys_flat) - 1)]
         # no shuffle: stride the flat key list by worker id (Q17).  The reference indexes keys_flat[worker id] unguarded and
         # raises IndexError when a database has fewer images than reader processes; wrap instead.
+        # With several shards (one reader per rank) worker w of shard s starts at s * nb_workers + w and strides by
+        # num_shards * nb_workers: together the ranks walk the key list exactly like one reader with all the workers.
         state['idx'] %= len(self.keys_flat)
         fn = self.keys_flat[state['idx']]
-        state['idx'] = (state['idx'] + self.nb_workers) % len(self.keys_flat)
+        state['idx'] = (state['idx'] + self.nb_workers * self.num_shards) % len(self.keys_flat)
         return fn
 
     def load_example(self, key, env):
@@ -326,7 +346,7 @@ class ImageReader:
         return (img, labels[0], labels[1], labels[2])
 
     def _image_loader(self, worker_id):
-        state = {'idx': worker_id}
+        state = {'idx': self.shard_index * self.nb_workers + worker_id}
         try:
             random.seed()
             np.random.seed((os.getpid() * 2654435761) % (2 ** 32))
@@ -346,7 +366,7 @@ class ImageReader:
         finally:
             self.outQ.put(None)
 
-    def get_example(self):
+    def _get_raw(self):
         if self.outQ.qsize() < int(0.1 * self.maxOutQSize):     # imagereader.py:424-430
             if not self.queue_starvation:
                 print('Input Queue Starvation !!!!')
@@ -356,9 +376,26 @@ class ImageReader:
             self.queue_starvation = False
         return self.outQ.get()
 
+    def get_example(self):
+        """imagereader.py:420-436: one (image, label_1, label_2, label_3) with the image z-scored (imagereader.py:398 does it
+        in the worker; here the workers hand out raw pixels because the batched path z-scores whole batches on the GPU, so the
+        single-example accessors normalise on the way out -- on the GPU as well, there is no host z-score in this package)."""
+        example = self._get_raw()
+        if example is None:
+            return None
+        return (zscore_normalize(example[0]),) + tuple(example[1:])
+
     def generator(self):
         while True:
             example = self.get_example()
+            if example is None:
+                return
+            yield example
+
+    def raw_generator(self):
+        """Examples as the workers produce them (image NOT z-scored): what Dataset.batch() stacks and normalises on the GPU."""
+        while True:
+            example = self._get_raw()
             if example is None:
                 return
             yield example

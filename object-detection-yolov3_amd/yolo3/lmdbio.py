@@ -10,10 +10,12 @@ liblmdb exists in this image, so the on-disk B+tree is handled here directly:
   node: {lo u16, hi u16, flags u16, ksize u16, key, data}; leaf data size = lo | hi << 16, F_BIGDATA (0x01) data is
                  the u64 page number of an overflow run; branch child page = lo | hi << 16 | flags << 32.
 
-Reader: read-only, memory-mapped, ordered iteration and point lookups.  Writer: builds a fresh environment from
-items in one pass (sorted by key like LMDB's default byte order), values above the node limit go to overflow
-pages.  PARITY UNPINNED: no liblmdb here to cross-check against; the writer follows the published format above and
-is verified by round trips through the reader (tests/test_cpu_dataplane.py).
+Reader: read-only, memory-mapped, ordered iteration and point lookups.  Writer: builds a fresh environment in one
+streaming pass over the keys in LMDB's default byte order: overflow runs (values above the node limit) and leaf pages
+go to the file as they fill up, only (first key, page number) per leaf stays in memory (the reference commits every
+1000 records into a 5 TB map, build_lmdb.py:80-100: a dataset never has to fit in RAM).
+PARITY UNPINNED: no liblmdb here to cross-check against and the reference ships no data.mdb; the writer follows the
+published format above and is verified by round trips through the reader (tests/test_cpu_dataplane.py).
 """
 import mmap
 import os
@@ -25,7 +27,7 @@ P_BRANCH, P_LEAF, P_OVERFLOW, P_META = 0x01, 0x02, 0x04, 0x08
 F_BIGDATA = 0x01
 MAGIC = 0xBEEFC0DE
 INVALID = 0xFFFFFFFFFFFFFFFF
-NODE_MAX = ((PAGE - HDR) // 2) & ~1   # mdb: me_nodemax = (((psize - PAGEHDRSZ) / MDB_MINKEYS) & -2) - sizeof(indx_t)
+NODE_MAX = (((PAGE - HDR) // 2) & ~1) - 2   # mdb: me_nodemax = (((psize - PAGEHDRSZ) / MDB_MINKEYS) & -2) - sizeof(indx_t) = 2038
 
 
 class LmdbError(Exception):
@@ -170,112 +172,122 @@ def _page_bytes(pgno, flags, nodes):
     return bytes(buf)
 
 
-def write_environment(path, items, map_size=None):
-    """Create <path>/data.mdb (+ an empty lock.mdb) holding ``items`` (iterable of (key bytes, value bytes)).
-    Keys must be unique; they are stored in LMDB's default (bytewise) order."""
+def write_environment_stream(path, sorted_keys, value_of, map_size=None):
+    """Create <path>/data.mdb (+ an empty lock.mdb).  ``sorted_keys``: unique key bytes in ascending byte order;
+    ``value_of(key)`` is called once per key, in that order, and its bytes are written out before the next call --
+    memory use is one leaf page plus one value, whatever the size of the dataset."""
     os.makedirs(path, exist_ok=True)
-    items = sorted(((bytes(k), bytes(v)) for k, v in items), key=lambda kv: kv[0])
-    for a, b in zip(items, items[1:]):
-        if a[0] == b[0]:
-            raise LmdbError('duplicate key %r' % a[0])
-    pages = {}           # pgno -> bytes (branch/leaf)
-    overflow = []        # (pgno, value)
     next_pg = [2]
-    n_leaf = n_branch = n_over = 0
+    counts = dict(leaf=0, branch=0, over=0, entries=0)
 
     def alloc(n=1):
         p = next_pg[0]
         next_pg[0] += n
         return p
 
-    # leaves
-    level = []           # (first key, pgno)
-    cur, cur_size, cur_first = [], HDR, None
+    with open(os.path.join(path, 'data.mdb'), 'wb') as fh:
+        def put_page(pg, data):
+            fh.seek(pg * PAGE)
+            fh.write(data)
 
-    def flush_leaf():
-        nonlocal cur, cur_size, cur_first, n_leaf
-        if not cur:
-            return
-        pg = alloc()
-        pages[pg] = _page_bytes(pg, P_LEAF, cur)
-        level.append((cur_first, pg))
-        n_leaf += 1
+        level = []           # (first key, pgno) of every leaf
         cur, cur_size, cur_first = [], HDR, None
 
-    for k, v in items:
-        if len(k) > 511:
-            raise LmdbError('key too long')
-        if 8 + len(k) + len(v) > NODE_MAX:
-            npg = (HDR + len(v) + PAGE - 1) // PAGE
-            ov = alloc(npg)
-            overflow.append((ov, npg, v))
-            n_over += npg
-            node = struct.pack('<HHHH', len(v) & 0xFFFF, len(v) >> 16, F_BIGDATA, len(k)) + k + struct.pack('<Q', ov)
-        else:
-            node = struct.pack('<HHHH', len(v) & 0xFFFF, len(v) >> 16, 0, len(k)) + k + v
-        need = ((len(node) + 1) & ~1) + 2
-        if cur_size + need > PAGE:
-            flush_leaf()
-        if cur_first is None:
-            cur_first = k
-        cur.append(node)
-        cur_size += need
-    flush_leaf()
+        def flush_leaf():
+            nonlocal cur, cur_size, cur_first
+            if not cur:
+                return
+            pg = alloc()
+            put_page(pg, _page_bytes(pg, P_LEAF, cur))
+            level.append((cur_first, pg))
+            counts['leaf'] += 1
+            cur, cur_size, cur_first = [], HDR, None
 
-    depth = 1 if level else 0
-    while len(level) > 1:
-        nxt = []
-        cur, cur_size, cur_first = [], HDR, None
-        for i, (k, pg) in enumerate(level):
-            key = b'' if not cur else k          # node 0 of a branch page carries no key
-            node = struct.pack('<HHHH', pg & 0xFFFF, (pg >> 16) & 0xFFFF, (pg >> 32) & 0xFFFF, len(key)) + key
+        prev = None
+        for k in sorted_keys:
+            k = bytes(k)
+            if prev is not None and k <= prev:
+                raise LmdbError('duplicate key %r' % k if k == prev else 'keys not in ascending order at %r' % k)
+            prev = k
+            if len(k) > 511:
+                raise LmdbError('key too long')
+            v = bytes(value_of(k))
+            counts['entries'] += 1
+            if 8 + len(k) + len(v) > NODE_MAX:
+                npg = (HDR + len(v) + PAGE - 1) // PAGE
+                ov = alloc(npg)
+                hdr = bytearray(HDR)
+                struct.pack_into('<QHHI', hdr, 0, ov, 0, P_OVERFLOW, npg)
+                put_page(ov, bytes(hdr) + v)
+                counts['over'] += npg
+                node = struct.pack('<HHHH', len(v) & 0xFFFF, len(v) >> 16, F_BIGDATA, len(k)) + k + struct.pack('<Q', ov)
+            else:
+                node = struct.pack('<HHHH', len(v) & 0xFFFF, len(v) >> 16, 0, len(k)) + k + v
             need = ((len(node) + 1) & ~1) + 2
-            if cur and cur_size + need > PAGE:
-                bp = alloc()
-                pages[bp] = _page_bytes(bp, P_BRANCH, cur)
-                nxt.append((cur_first, bp))
-                n_branch += 1
-                cur, cur_size, cur_first = [], HDR, None
-                node = struct.pack('<HHHH', pg & 0xFFFF, (pg >> 16) & 0xFFFF, (pg >> 32) & 0xFFFF, 0)
-                need = ((len(node) + 1) & ~1) + 2
+            if cur_size + need > PAGE:
+                flush_leaf()
             if cur_first is None:
                 cur_first = k
             cur.append(node)
             cur_size += need
-        if cur:
-            bp = alloc()
-            pages[bp] = _page_bytes(bp, P_BRANCH, cur)
-            nxt.append((cur_first, bp))
-            n_branch += 1
-        level = nxt
-        depth += 1
-    root = level[0][1] if level else INVALID
-    last_pg = next_pg[0] - 1
-    if map_size is None:
-        map_size = max(1 << 20, (last_pg + 1) * PAGE)
+        flush_leaf()
 
-    def meta(pgno, txnid):
-        buf = bytearray(PAGE)
-        struct.pack_into('<QHHHH', buf, 0, pgno, 0, P_META, 0, 0)
-        off = HDR
-        struct.pack_into('<IIQQ', buf, off, MAGIC, 1, 0, map_size)
-        struct.pack_into('<IHHQQQQQ', buf, off + 24, PAGE, 0, 0, 0, 0, 0, 0, INVALID)                  # FREE_DBI
-        struct.pack_into('<IHHQQQQQ', buf, off + 72, 0, 0, depth, n_branch, n_leaf, n_over, len(items), root)   # MAIN_DBI
-        struct.pack_into('<QQ', buf, off + 120, max(last_pg, 1), txnid)
-        return bytes(buf)
+        depth = 1 if level else 0
+        while len(level) > 1:
+            nxt = []
+            cur, cur_size, cur_first = [], HDR, None
+            for k, pg in level:
+                key = b'' if not cur else k          # node 0 of a branch page carries no key
+                node = struct.pack('<HHHH', pg & 0xFFFF, (pg >> 16) & 0xFFFF, (pg >> 32) & 0xFFFF, len(key)) + key
+                need = ((len(node) + 1) & ~1) + 2
+                if cur and cur_size + need > PAGE:
+                    bp = alloc()
+                    put_page(bp, _page_bytes(bp, P_BRANCH, cur))
+                    nxt.append((cur_first, bp))
+                    counts['branch'] += 1
+                    cur, cur_size, cur_first = [], HDR, None
+                    node = struct.pack('<HHHH', pg & 0xFFFF, (pg >> 16) & 0xFFFF, (pg >> 32) & 0xFFFF, 0)
+                    need = ((len(node) + 1) & ~1) + 2
+                if cur_first is None:
+                    cur_first = k
+                cur.append(node)
+                cur_size += need
+            if cur:
+                bp = alloc()
+                put_page(bp, _page_bytes(bp, P_BRANCH, cur))
+                nxt.append((cur_first, bp))
+                counts['branch'] += 1
+            level = nxt
+            depth += 1
+        root = level[0][1] if level else INVALID
+        last_pg = next_pg[0] - 1
+        if map_size is None:
+            map_size = max(1 << 20, (last_pg + 1) * PAGE)
 
-    with open(os.path.join(path, 'data.mdb'), 'wb') as fh:
-        fh.write(meta(0, 0))
-        fh.write(meta(1, 1))
+        def meta(pgno, txnid):
+            buf = bytearray(PAGE)
+            struct.pack_into('<QHHHH', buf, 0, pgno, 0, P_META, 0, 0)
+            off = HDR
+            struct.pack_into('<IIQQ', buf, off, MAGIC, 1, 0, map_size)
+            struct.pack_into('<IHHQQQQQ', buf, off + 24, PAGE, 0, 0, 0, 0, 0, 0, INVALID)                  # FREE_DBI
+            struct.pack_into('<IHHQQQQQ', buf, off + 72, 0, 0, depth, counts['branch'], counts['leaf'], counts['over'], counts['entries'], root)   # MAIN_DBI
+            struct.pack_into('<QQ', buf, off + 120, max(last_pg, 1), txnid)
+            return bytes(buf)
+
+        put_page(0, meta(0, 0))
+        put_page(1, meta(1, 1))
         fh.truncate((last_pg + 1) * PAGE)
-        for pg, b in pages.items():
-            fh.seek(pg * PAGE)
-            fh.write(b)
-        for ov, npg, v in overflow:
-            hdr = bytearray(HDR)
-            struct.pack_into('<QHHI', hdr, 0, ov, 0, P_OVERFLOW, npg)
-            fh.seek(ov * PAGE)
-            fh.write(hdr)
-            fh.write(v)
     open(os.path.join(path, 'lock.mdb'), 'ab').close()
-    return len(items)
+    return counts['entries']
+
+
+def write_environment(path, items, map_size=None):
+    """``items``: iterable of (key bytes, value bytes) held in memory (tests, small sets); keys must be unique and are
+    stored in LMDB's default (bytewise) order.  Large datasets: write_environment_stream."""
+    table = {}
+    for k, v in items:
+        k = bytes(k)
+        if k in table:
+            raise LmdbError('duplicate key %r' % k)
+        table[k] = v
+    return write_environment_stream(path, sorted(table), table.__getitem__, map_size)

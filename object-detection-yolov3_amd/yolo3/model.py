@@ -675,9 +675,10 @@ class YoloV3:
             out.append(d)
         return out
 
-    def get_weights(self):
+    def get_weights(self, moving=None):
+        """moving: optional replacement for self.moving (the cross-replica MEAN a checkpoint stores, parallel.mean_moving_stats)."""
         out = self._unpack(self.params)
-        mov = self.moving.detach().cpu().numpy()
+        mov = (self.moving if moving is None else moving).detach().cpu().numpy()
         for sp, d in zip(self.specs, out):
             if sp.bn:
                 d['mean'] = mov[sp.mv_off:sp.mv_off + sp.cout].copy()
@@ -695,10 +696,10 @@ class YoloV3:
             out += [d['W'], d['b']] + ([d['gamma'], d['beta']] if sp.bn else [])
         return out
 
-    def save_weights(self, path):
+    def save_weights(self, path, moving=None):
         """Own weight file (the reference's TF checkpoint / SavedModel formats need TF)."""
         flat = {}
-        for i, d in enumerate(self.get_weights()):
+        for i, d in enumerate(self.get_weights(moving)):
             for k, v in d.items():
                 flat['l%03d_%s' % (i, k)] = v
         flat['meta_img_size'] = np.asarray(self.img_size, np.int64)

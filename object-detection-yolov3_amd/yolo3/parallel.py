@@ -84,8 +84,10 @@ class DataParallel:
         return t
 
     def mean_moving_stats(self, moving):
-        """BN moving statistics are per-replica sync-on-read variables aggregated by MEAN when saved (App. C4)."""
+        """BN moving statistics are per-replica sync-on-read variables: reading them (a checkpoint save) aggregates by MEAN
+        (App. C4) and leaves every replica's own running value untouched.  Returns the mean as a NEW tensor."""
+        out = moving.detach().clone()
         if self.world_size > 1:
-            dist.all_reduce(moving, op=dist.ReduceOp.SUM, group=self.group)
-            moving /= self.world_size
-        return moving
+            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+            out /= self.world_size
+        return out

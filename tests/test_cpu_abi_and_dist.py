@@ -111,7 +111,9 @@ def _dp_worker(rank, world, port, q):
         dp.on_layer_done(i)
     dp.finish_step()
     loss = dp.reduce_sum(torch.tensor(1.0 + rank))
-    mov = dp.mean_moving_stats(torch.full((4,), float(rank)))
+    own = torch.full((4,), float(rank))
+    mov = dp.mean_moving_stats(own)
+    assert mov is not own and bool((own == float(rank)).all())      # sync-on-read: the replica's own value is untouched
     q.put((rank, mine.numpy(), m.grads.numpy(), params.numpy(), float(loss), mov.numpy(), len(dp.buckets)))
     dist.barrier()
     dist.destroy_process_group()

@@ -97,12 +97,31 @@ def test_image_reader_surface(tmp_path):
     assert l1.shape == (2, 2, 2, 7) and l3.shape == (8, 8, 2, 7)
     # worker processes + bounded queue + orderly shutdown
     rd.startup()
-    gen = rd.generator()
+    gen = rd.raw_generator()                          # generator() / get_example() z-score on the GPU: tests/test_gpu_cli.py
     seen = [next(gen) for _ in range(7)]
     assert all(s[0].shape == (3, 64, 64) for s in seen)
     rd.shutdown()
     with pytest.raises(Exception):
         ImageReader(str(tmp_path / 'absent.lmdb'), anchors)
+
+
+def test_unshuffled_reader_shards_are_disjoint(tmp_path):
+    """One reader per rank (train.py under torch.distributed.run): worker w of shard s starts at s * workers + w and strides by
+    shards * workers, so the ranks' test readers together walk the key list once, without overlap."""
+    from yolo3.imagereader import ImageReader
+    path, _ = _make_db(tmp_path, n=12, size=(64, 64, 3), seed=2)
+    anchors = [(64, 384), (384, 64)]
+    walked = []
+    for shard in range(2):
+        rd = ImageReader(path, anchors, use_augmentation=False, shuffle=False, num_workers=3, num_shards=2, shard_index=shard)
+        for w in range(3):
+            state = {'idx': rd.shard_index * rd.nb_workers + w}
+            walked += [rd._next_key(state) for _ in range(2)]
+        ds = rd.get_tf_dataset().shard(2, shard)          # consistent request: accepted
+        assert ds.reader is rd
+    assert sorted(walked) == rd.keys_flat and len(set(walked)) == 12
+    rd.set_shard(2, 0)                                    # not started yet: may still change
+    assert rd.shard_index == 0
 
 
 def test_image_reader_augmentation_keeps_contract(tmp_path):

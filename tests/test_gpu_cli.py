@@ -89,6 +89,27 @@ def test_dataset_prefetch_matches_plain_batches(tmp_path):
     assert not any(t.name == 'yolo3-prefetch' and t.is_alive() for t in threading.enumerate())
 
 
+def test_get_example_is_zscored(tmp_path):
+    """The single-example accessors keep the reference's contract (imagereader.py:398,420-436): the image comes out
+    z-scored with its own mean / population std (the workers hand out raw pixels for the batched GPU path)."""
+    from test_cpu_dataplane import _make_db
+    from yolo3.imagereader import ImageReader
+    path, truth = _make_db(tmp_path, n=6, size=(64, 64, 3), seed=4)
+    rd = ImageReader(path, [(64, 384), (384, 64)], use_augmentation=False, shuffle=False, num_workers=1)
+    rd.startup()
+    try:
+        ex = rd.get_example()
+        it = iter(rd.get_tf_dataset())                   # unbatched dataset: same contract
+        ex2 = next(it)
+    finally:
+        rd.shutdown()
+    for e, key in ((ex, rd.keys_flat[0]), (ex2, rd.keys_flat[1])):
+        raw = truth[key][0].transpose(2, 0, 1).astype(np.float64)
+        want = (raw - raw.mean()) / raw.std()
+        assert e[0].dtype == np.float32 and abs(float(e[0].mean())) < 1e-5 and abs(float(e[0].std()) - 1.0) < 1e-4
+        np.testing.assert_allclose(e[0], want, atol=2e-5)
+
+
 def _write_dataset(tmp, n, size, K=2, seed=5):
     sys.path.insert(0, PKG)
     import build_lmdb

@@ -62,9 +62,10 @@ def test_set_get_weights_roundtrip():
     assert len(yolo.trainable_weights()) == 294
 
 
-@pytest.mark.parametrize('img,n', [(96, 3), (416, 1)])
+@pytest.mark.parametrize('img,n', [(96, 3), (416, 1), (416, 8)])
 def test_inference_matches_oracle(img, n):
-    """predict(): conv stacks with folded BN + residuals + upsample/concat + decode."""
+    """predict(): conv stacks with folded BN + residuals + upsample/concat + decode.  (416, 8) is BASELINE.json
+    configs[1] at its full size: the launch planner picks other tiles / split-K factors there than at n = 1."""
     om, params, yolo, images, _ = _setup(img, n, 7, True)
     out = yolo.predict(images.cuda()).cpu().numpy()
     refs = {}
@@ -122,13 +123,14 @@ def test_bf16_inference_matches_bf16_oracle(img, n):
     assert torch.equal(yolo2.predict(images.cuda()).cpu(), torch.from_numpy(out16))    # constructor default, deterministic
 
 
-def test_bf16_layers_teacher_forced():
-    """Every layer of the bf16 plan on its own: the oracle (fp64 arithmetic, bf16 rounding points) recomputes layer i
+@pytest.mark.parametrize('img,n', [(96, 2), (608, 2)])
+def test_bf16_layers_teacher_forced(img, n):
+    """(608 = the tile size of BASELINE.json configs[4]: the real model on a batch of full-size tiles.)
+    Every layer of the bf16 plan on its own: the oracle (fp64 arithmetic, bf16 rounding points) recomputes layer i
     from the GPU's OWN bf16 inputs (teacher forcing), so nothing compounds.  Bound per element against the oracle's
     value BEFORE rounding: half a bf16 ulp (round to nearest; a tie or near-tie may legitimately fall either way, which
     is why the comparison is not against the oracle's rounded value) plus 3e-5 of the layer's scale for fp32
     accumulation order / the folded BatchNorm affine."""
-    img, n = 96, 2
     om, params, yolo, images, _ = _setup(img, n, 11, True)
     yolo.predict(images.cuda(), precision='bf16')
     plan = yolo._plan(n, False, True)
@@ -163,11 +165,12 @@ def test_bf16_layers_teacher_forced():
         assert bool(assert_fm), 'head %d' % j
 
 
-def test_train_step_matches_oracle():
+@pytest.mark.parametrize('img,n', [(96, 4), (416, 8)])
+def test_train_step_matches_oracle(img, n):
     """train_step(): forward with batch statistics, loss, full backward (dgrad/wgrad/BN/upsample), Keras Adam,
     moving-stat update.  Step 1 is compared tensor by tensor; step 2 only through its loss, because the first Adam
-    step moves every weight by ~lr*sign(g) and the sign of a numerically-zero gradient is implementation noise."""
-    img, n = 96, 4
+    step moves every weight by ~lr*sign(g) and the sign of a numerically-zero gradient is implementation noise.
+    (416, 8) is the benchmarked step (BASELINE.json configs[2]) at its full size."""
     om, params, yolo, images, gts = _setup(img, n, 11, False)
     gbs = n
     res = {}
