@@ -64,8 +64,13 @@ int y3_conv2d_fwd(const y3_tensor* src, const float* wt, const float* bias, int 
                   const y3_tensor* dst, unsigned flags, float alpha,
                   const float* scale, const float* shift, const y3_tensor* resid,
                   float* stats, void* workspace, size_t workspace_bytes, y3_stream_t stream);
-/* m = output pixels (N*OH*OW).  Layers with few output tiles are split along K; the partial slabs live in
- * `workspace` (y3_conv2d_fwd_workspace bytes; passing less only disables the split when stats == NULL). */
+/* m = output pixels (N*OH*OW).  Launches whose tile count does not fill the 256 CUs evenly are split along K (all
+ * tiles, or only the remainder round); the slices park raw partial sums in `workspace` and the slice of a tile that
+ * finishes last reduces them in slice order inside the same kernel (bit-reproducible; no second launch).
+ * WORKSPACE CONTRACT (y3_conv2d_fwd / _dgrad / _wgrad): the first 256 KiB of a workspace are per-tile tickets.  Zero
+ * the workspace once after allocating it (hipMemset, or y3_fill); every launch leaves the tickets at zero.  Launches
+ * that share a workspace must be ordered on one stream.  Passing less than y3_conv2d_*_workspace() bytes disables
+ * the split (forward / data gradient) or is an error (kernel gradient). */
 int y3_conv2d_stats_tiles(int m, int cin, int ksize, int cout);
 size_t y3_conv2d_fwd_workspace(int m, int cin, int ksize, int cout);
 
@@ -83,7 +88,8 @@ size_t y3_conv2d_dgrad_workspace(const y3_tensor* ddst, int ksize, int stride, c
 
 /*
  * Gradient w.r.t. the kernel:  dw[tap][ci][co] = sum_pixels src*ddst.
- * workspace: y3_conv2d_wgrad_workspace() bytes (split-K partial slabs).
+ * The pixel axis is split over workgroups; the last split of a (k-tile, n-tile) to finish sums the partial slabs in
+ * split order inside the kernel.  workspace: y3_conv2d_wgrad_workspace() bytes, zeroed once (contract above).
  */
 int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride,
                     float* dw, void* workspace, size_t workspace_bytes, y3_stream_t stream);
@@ -122,7 +128,10 @@ int y3_bn_apply(const y3_tensor* a, const float* scale, const float* shift, cons
                 const y3_tensor* y, y3_stream_t stream);
 /*
  * Backward of conv_layer's tail  y = BN(lrelu(z)):  given dy and a = lrelu(z)
- *   step 1 (reduce):   per-channel partial sums -> workspace
+ *   step 1 (reduce):   per-channel partial sums (raw moments of (dy, a), fp64) -> workspace.
+ *                      Channels: c % 4 == 0, c <= 1024 and (c / 4) must divide 256 (true for every layer of
+ *                      this network: 32 ... 1024); save_mean / save_rstd / alpha are accepted for symmetry
+ *                      and used by step 2 only.
  *   step 2 (finalize): dgamma, dbeta, dbias (bias gradient of the conv) and
  *                      the per-channel coefficients k1,k2,k3 (coef[3][c])
  *   step 3 (apply):    dz = (k1*dy + k2*a + k3) * (a > 0 ? 1 : alpha)
@@ -130,7 +139,7 @@ int y3_bn_apply(const y3_tensor* a, const float* scale, const float* shift, cons
 int y3_bn_bwd_reduce(const y3_tensor* dy, const y3_tensor* a, const float* save_mean,
                      const float* save_rstd, float alpha, float* partials, int* nparts,
                      y3_stream_t stream);
-int y3_bn_bwd_partials(int m, int c); /* number of partial rows; `partials` holds rows*5*c DOUBLES (8-byte aligned) */
+int y3_bn_bwd_partials(int m, int c); /* number of partial rows; `partials` holds rows*6*c DOUBLES (16-byte aligned) */
 int y3_bn_bwd_finalize(const float* partials, int nparts, int c, int count, const float* gamma,
                        const float* save_mean, const float* save_rstd, float alpha,
                        float* dgamma, float* dbeta, float* dbias, float* coef, y3_stream_t stream);

@@ -19,6 +19,9 @@
 // (lane half h takes k = 8*kk + 4*h + i), which only reorders the fp32 sum.
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 
 struct ConvArgs {
@@ -277,6 +280,7 @@ struct FastArgs {
     float* stats;
     int tap_off[9];   // byte offset of tap t from the pixel base (biased, >= 0)
     int tap_wrow[9];  // weight row of tap t, channel 0
+    int tg_nx, tg_off0, tg_offy, tg_offx, tg_w0, tg_wy, tg_wx;   // the same two tables as affine maps of the tap grid (tap = ty * tg_nx + tx)
     int tap_dh[9], tap_dw[9];
     unsigned src_bytes, wt_bytes, dst_bytes, resid_bytes;  // extents for the buffer descriptors
     int ntaps;
@@ -288,13 +292,63 @@ struct FastArgs {
     unsigned flags;
     float alpha;
     int nbn;
-    int ksplit, kchunk;  // split-K: grid = tiles * ksplit, slice z covers K range [z*kchunk, (z+1)*kchunk)
-    float* slab;         // [ksplit][M][Nout] raw partial sums when ksplit > 1
+    // Split-K with the reduction inside the kernel.  Work items: tiles [0, sk_f) are cut into sk_s0 K slices each, tiles
+    // [sk_f, tiles) into sk_s1 (the remainder of a launch whose tile count is not a multiple of the CU count is split
+    // finer so that every CU ends up with the same amount of MFMA work).  Item i < sk_n0 = sk_f * sk_s0 is slice
+    // i % sk_s0 of tile i / sk_s0; item i >= sk_n0 is slice (i - sk_n0) % sk_s1 of tile sk_f + (i - sk_n0) / sk_s1.  A slice
+    // covers sk_chunk{0,1} K steps.  Slices of a split tile park their raw accumulators in `slab` (item-major, fragment
+    // order) and take a ticket; the slice that draws the last ticket re-reads ALL of them in slice order (fixed order ->
+    // bit-reproducible), runs the normal epilogue and leaves the ticket at zero for the next launch.
+    int sk_f, sk_n0, sk_s0, sk_s1, sk_chunk0, sk_chunk1;
+    int sk_slab0;        // first item that owns a slab slot (0, or sk_n0 when only the remainder tiles are split)
+    float* slab;
+    int* tickets;        // one per tile, zero before the launch
+    int stagger;         // units of 256 cycles by which co-resident workgroups are pushed out of phase before the K loop
 };
 
 #define Y3_OOB 0x80000000u
 
-template <int BM, int BN, int WM, int WN, int BK, bool DENSE>
+// Development instrumentation (tools/probe/conv_timing.hip builds this file with -DY3_TIMING): per-workgroup s_memtime
+// stamps of the kernel phases + the CU the workgroup ran on.  Compiled out of the product library.
+#ifdef Y3_TIMING
+__device__ int y3_abl_dev = 0;   // ablation mask for the probe: 1 = no global loads in the K loop, 2 = no LDS stores, 4 = no barrier
+#define Y3_ABL(bit) (y3_abl_dev & (bit))
+__device__ unsigned long long* y3_timing_buf = nullptr;
+#define Y3_TSTAMP(i)                                                                                                    \
+    do {                                                                                                                \
+        if (y3_timing_buf && threadIdx.x == 0) y3_timing_buf[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define Y3_TSTAMP(i)
+#define Y3_ABL(bit) 0
+#endif
+
+template <int... I, class F>
+__device__ __forceinline__ void y3_for_each_ic(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// Workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it (a plain
+// __syncthreads() also waits for vmcnt(0)).
+__device__ __forceinline__ void y3_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// Instruction-mix directives for the machine scheduler (masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write)
+template <int MASK, int N>
+__device__ __forceinline__ void y3_sgb() {
+    if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
+}
+template <int COUNT, int MASK, int MFMAS = 1>
+__device__ __forceinline__ void y3_sgb_pairs() {   // COUNT x { MFMAS matrix instructions, then one instruction of MASK }
+    if constexpr (COUNT > 0) {
+        y3_sgb<0x008, MFMAS>();
+        y3_sgb<MASK, 1>();
+        y3_sgb_pairs<COUNT - 1, MASK, MFMAS>();
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int BK, bool DENSE, int PIPE = 0>
 __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int bid0) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int LDA = BK + 4;
@@ -309,16 +363,36 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int bid0
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
     __shared__ float red[2][WM][BN];
 
+    Y3_TSTAMP(0);
+#ifdef Y3_TIMING
+    if (y3_timing_buf && threadIdx.x == 0) {
+        y3_timing_buf[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+        y3_timing_buf[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+        y3_timing_buf[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int kz = bid0 % p.ksplit;
-    const int bid = bid0 / p.ksplit;
+    int bid, kz, nz, kchunk;
+    if (bid0 < p.sk_n0) {
+        bid = bid0 / p.sk_s0;
+        kz = bid0 - bid * p.sk_s0;
+        nz = p.sk_s0;
+        kchunk = p.sk_chunk0;
+    } else {
+        const int t = bid0 - p.sk_n0;
+        const int q = t / p.sk_s1;
+        bid = p.sk_f + q;
+        kz = t - q * p.sk_s1;
+        nz = p.sk_s1;
+        kchunk = p.sk_chunk1;
+    }
     const int bm = bid / p.nbn, bn = bid % p.nbn;
     const int m0 = bm * BM, n0 = bn * BN;
     const int ohw = p.OH * p.OW;
-    const int kbeg = kz * p.kchunk;
-    const int kend = min(p.K, kbeg + p.kchunk);
+    const int kbeg = kz * kchunk * BK;
+    const int kend = min(p.K, kbeg + kchunk * BK);
 
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.wt_bytes, 0x00020000);
@@ -354,19 +428,37 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int bid0
     }
 
     f32x4 ra[A_LOADS], rb[B_LOADS];
-    auto gload = [&](int k0) {
-        const int tap = k0 >> p.logC;  // wave-uniform: scalar unit
-        const int cb = k0 & p.cmask;
-        const unsigned a_soff = (unsigned)(p.tap_off[tap] + cb * 4);
-        const unsigned b_soff = (unsigned)((p.tap_wrow[tap] + cb) * p.Nout) * 4u;
+    // Tap -> (source offset, weight row) without a table: indexing the argument-segment tables with a run-time tap is a scalar
+    // MEMORY load, and an SMEM load in flight forces every later LDS wait to lgkmcnt(0) (scalar loads return out of order),
+    // which stalls the MFMA stream on the fragment reads just issued (a register copy of the tables was turned into a
+    // scratch array by the compiler: worse).  Every tap list this kernel sees is a (rows x tg_nx) grid in row-major order
+    // (3x3, 1x1, and the 1/2/2/4-tap parity classes of a stride-2 data gradient), so both quantities are affine in the
+    // grid coordinates: a few scalar ALU instructions.
+    struct Soff {
+        int tap, cb, toff, wrow;
+    };
+    auto soff_prep = [&](int k0) {
+        Soff o;
+        o.tap = k0 >> p.logC;  // wave-uniform: scalar unit
+        o.cb = k0 & p.cmask;
+        const int ty = p.tg_nx == 1 ? o.tap : (p.tg_nx == 2 ? o.tap >> 1 : (o.tap * 11) >> 5);   // tap / tg_nx for tap < 9
+        const int tx = o.tap - ty * p.tg_nx;
+        o.toff = p.tg_off0 + ty * p.tg_offy + tx * p.tg_offx;
+        o.wrow = p.tg_w0 + ty * p.tg_wy + tx * p.tg_wx;
+        return o;
+    };
+    auto gload_at = [&](const Soff& o) {
+        const unsigned a_soff = (unsigned)(o.toff + o.cb * 4);
+        const unsigned b_soff = (unsigned)((o.wrow + o.cb) * p.Nout) * 4u;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const unsigned vo = ((a_mask[i] >> tap) & 1u) ? a_voff[i] : Y3_OOB;
+            const unsigned vo = ((a_mask[i] >> o.tap) & 1u) ? a_voff[i] : Y3_OOB;
             ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, vo, a_soff, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[i], b_soff, 0);
     };
+    auto gload = [&](int k0) { gload_at(soff_prep(k0)); };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) *reinterpret_cast<f32x4*>(&As[buf][((tid + i * THREADS) / KV) * LDA + a_kv * 4]) = ra[i];
@@ -386,13 +478,196 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int bid0
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (kend - kbeg) / BK;
+    if (p.stagger > 0) {
+        // Workgroups are dealt to the CUs in launch order: blocks b, b + 256, b + 512 share a CU and start together, run
+        // the same program and would reach their barriers (and leave the matrix pipe idle) together.  Delay the later
+        // generations once so that their K steps interleave (MI355X_MICROARCH.md, two waves per SIMD, item 9).
+        const int gen = ((int)blockIdx.x >> 8) % 3;
+        for (int i = 0; i < gen * p.stagger; ++i) __builtin_amdgcn_s_sleep(4);
+    }
+    if constexpr (PIPE == 2 && BK == 16) {
+        // Software-pipelined K loop, interleaved by hand.  A wave issues MFMAs in order and cannot queue them: once an MFMA
+        // has issued, only the 64 cycles it executes are free for other instructions, so memory instructions left in a block
+        // between two MFMA groups idle the matrix pipe (measured with tools/probe/conv_timing: 2 758 cycles per step for
+        // 2 048 of MFMA with that layout and everything else ablated).  Here every MFMA is followed by at most one or two
+        // memory instructions (a "slot"), fenced with sched_barrier so that the compiler keeps the order:
+        //   group 0 (fragment set 0):  slots carry the LDS reads of set 1 (this step's second half), then the LDS stores of
+        //                              the NEXT step's tile (global data loaded one step earlier)
+        //   LDS-only barrier            publishes the next buffer; global loads stay in flight across it
+        //   group 1 (fragment set 1):  slots carry the global loads for the step after next, then the LDS reads of the next
+        //                              step's set 0
+        // The last two K steps are peeled, so the steady-state body has no branches.
+        f32x4 fa[2][MB];
+        float fb[2][NB][4];
+        constexpr int NM = MB * NB * 4;             // MFMAs per group
+        constexpr int NW = A_LOADS + B_LOADS;       // LDS stores = global loads per K step
+        const float* as_base = &As[0][(wm * TM + l31) * LDA + lh * 4];
+        const float* bs_base = &Bs[0][(lh * 4) * BN + wn * TN + l31];
+        constexpr int ABUF = BM * LDA, BBUF = BK * BN;
+        // events of a half step, in issue order.  group 0: MB reads (A), 2 reads (B, q pairs), NW stores.
+        //                                        group 1: NW global loads, MB reads (A), 2 reads (B).
+        constexpr int NE = MB + 2 + NW;
+        Soff nxt;
+        int knext = 0;
+        auto event = [&](auto G, auto E, auto H1, auto H2, int cur) {
+            constexpr int g = decltype(G)::value, e = decltype(E)::value;
+            constexpr bool h1 = decltype(H1)::value, h2 = decltype(H2)::value;
+            if constexpr (g == 0) {
+                // fragment set 1 <- group 1 of the current buffer; then stores of the next tile
+                if constexpr (e < MB) {
+                    fa[1][e] = *reinterpret_cast<const f32x4*>(as_base + cur * ABUF + e * 32 * LDA + 8);
+                } else if constexpr (e < MB + 2) {
+                    constexpr int q0 = (e - MB) * 2;
+#pragma unroll
+                    for (int q = q0; q < q0 + 2; ++q)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) fb[1][j][q] = bs_base[cur * BBUF + (8 + q) * BN + j * 32];
+                } else if constexpr (h1) {
+                    constexpr int w = e - MB - 2;
+                    if (!Y3_ABL(2)) {
+                        if constexpr (w < A_LOADS) {
+                            *reinterpret_cast<f32x4*>(&As[cur ^ 1][((tid + w * THREADS) / KV) * LDA + a_kv * 4]) = ra[w];
+                        } else {
+                            constexpr int wb = w - A_LOADS;
+                            const int idx = tid + wb * THREADS;
+                            if (B_TOTAL % THREADS == 0 || idx < B_TOTAL) *reinterpret_cast<f32x4*>(&Bs[cur ^ 1][(idx / BN4) * BN + (idx % BN4) * 4]) = rb[wb];
+                        }
+                    }
+                }
+            } else {
+                if constexpr (e < NW) {
+                    if constexpr (h2) {
+                        if (!Y3_ABL(1)) {
+                            if constexpr (e < A_LOADS) {
+                                const unsigned vo = ((a_mask[e] >> nxt.tap) & 1u) ? a_voff[e] : Y3_OOB;
+                                ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, vo, (unsigned)(nxt.toff + nxt.cb * 4), 0);
+                            } else {
+                                rb[e - A_LOADS] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[e - A_LOADS], (unsigned)((nxt.wrow + nxt.cb) * p.Nout) * 4u, 0);
+                            }
+                        }
+                    }
+                } else if constexpr (h1) {
+                    // fragment set 0 <- group 0 of the NEXT buffer
+                    if constexpr (e < NW + MB) {
+                        constexpr int i = e - NW;
+                        fa[0][i] = *reinterpret_cast<const f32x4*>(as_base + (cur ^ 1) * ABUF + i * 32 * LDA);
+                    } else {
+                        constexpr int q0 = (e - NW - MB) * 2;
+#pragma unroll
+                        for (int q = q0; q < q0 + 2; ++q)
+#pragma unroll
+                            for (int j = 0; j < NB; ++j) fb[0][j][q] = bs_base[(cur ^ 1) * BBUF + q * BN + j * 32];
+                    }
+                }
+            }
+        };
+        auto half = [&](auto G, auto H1, auto H2, int cur) {
+            constexpr int g = decltype(G)::value;
+            y3_for_each_ic(std::make_integer_sequence<int, NM>{}, [&](auto M) {
+                constexpr int m = decltype(M)::value;
+                constexpr int q = m / (MB * NB), i = (m / NB) % MB, j = m % NB;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][i][q], fb[g][j][q], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // this slot's share of the NE events (spread evenly when there are more events than MFMAs)
+                constexpr int e0 = NE <= NM ? m : m * NE / NM, e1 = NE <= NM ? (m < NE ? m + 1 : m) : (m + 1) * NE / NM;
+                y3_for_each_ic(std::make_integer_sequence<int, e1 - e0>{}, [&](auto D) { event(G, std::integral_constant<int, e0 + decltype(D)::value>{}, H1, H2, cur); });
+                // the scalar arithmetic for the NEXT iteration's global-load offsets rides in the slot after this one's loads
+                if constexpr (g == 1 && decltype(H2)::value && m == (NW < NM ? NW : NM - 1)) nxt = soff_prep(min(knext, kend - BK));
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        auto step = [&](auto H1, auto H2, int ks) {
+            const int cur = ks & 1;
+            knext = kbeg + (ks + 3) * BK;
+            half(std::integral_constant<int, 0>{}, H1, H2, cur);
+            if constexpr (decltype(H1)::value) {
+                if (!Y3_ABL(4)) y3_lds_barrier();
+            }
+            half(std::integral_constant<int, 1>{}, H1, H2, cur);
+        };
+        gload(kbeg);
+        lstore(0);
+        __syncthreads();
+        Y3_TSTAMP(1);
+        if (nk > 1) gload(kbeg + BK);
+        nxt = soff_prep(nk > 2 ? kbeg + 2 * BK : kbeg);      // offsets of the loads issued in iteration 0 (K step 2)
+        {   // fragment set 0 of step 0
+#pragma unroll
+            for (int i = 0; i < MB; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(as_base + i * 32 * LDA);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fb[0][j][q] = bs_base[q * BN + j * 32];
+        }
+        int ks = 0;
+        for (; ks + 2 < nk; ++ks) step(std::true_type{}, std::true_type{}, ks);
+        if (ks + 1 < nk) {
+            step(std::true_type{}, std::false_type{}, ks);
+            ++ks;
+        }
+        step(std::false_type{}, std::false_type{}, ks);
+    } else if constexpr (PIPE == 1) {
+        // Software-pipelined K loop.  A wave's only exposed synchronisation per K step is the barrier itself: fragments
+        // of MFMA group g+1 are read from LDS while group g is on the matrix pipe, the barrier sits BEFORE the last
+        // group of the step, and the first fragments of the next step are fetched (from the buffer the barrier just
+        // published) under that last group.  Global loads run two K steps ahead of their use (issued after the barrier,
+        // so its vmcnt(0) never waits for them; stored to LDS one step later).
+        constexpr int NG = BK / 8;
+        static_assert(NG % 2 == 0, "fragment double buffering assumes an even number of MFMA groups per K step");
+        f32x4 fa[2][MB];
+        float fb[2][NB][4];
+        auto ldf = [&](int buf, int g, int set) {
+            const float* as = &As[buf][(wm * TM + l31) * LDA + lh * 4];
+            const float* bs = &Bs[buf][(lh * 4) * BN + wn * TN + l31];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDA + g * 8);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fb[set][j][q] = bs[(g * 8 + q) * BN + j * 32];
+        };
+        auto mma = [&](int set) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][q], fb[set][j][q], acc[i][j], 0, 0, 0);
+        };
+        gload(kbeg);
+        lstore(0);
+        __syncthreads();
+        Y3_TSTAMP(1);
+        if (nk > 1) gload(kbeg + BK);
+        Soff nxt = soff_prep(nk > 2 ? kbeg + 2 * BK : kbeg);      // offsets of the loads issued in iteration 0 (K step 2)
+        ldf(0, 0, 0);
+        for (int ks = 0; ks < nk; ++ks) {
+            const int cur = ks & 1;
+#pragma unroll
+            for (int g = 0; g + 1 < NG; ++g) {
+                ldf(cur, g + 1, (g + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(g & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ks + 1 < nk && !Y3_ABL(2)) lstore(cur ^ 1);      // every wave finished reading that buffer before the previous barrier
+            if (!Y3_ABL(4)) __syncthreads();
+            if (ks + 2 < nk && !Y3_ABL(1)) gload_at(nxt);
+            if (ks + 1 < nk) ldf(cur ^ 1, 0, 0);
+            nxt = soff_prep(ks + 3 < nk ? kbeg + (ks + 3) * BK : kbeg);   // scalar loads: back before the next barrier
+            __builtin_amdgcn_sched_barrier(0);
+            mma((NG - 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
     gload(kbeg);
     lstore(0);
     __syncthreads();
+    Y3_TSTAMP(1);
     int cur = 0;
     for (int ks = 0; ks < nk; ++ks) {
         const bool more = ks + 1 < nk;
-        if (more) gload(kbeg + (ks + 1) * BK);
+        if (more && !Y3_ABL(1)) gload(kbeg + (ks + 1) * BK);
         const float* as = &As[cur][(wm * TM + l31) * LDA + lh * 4];
         const float* bs = &Bs[cur][(lh * 4) * BN + wn * TN + l31];
 #pragma unroll
@@ -412,26 +687,61 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int bid0
 #pragma unroll
                     for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
         }
-        if (more) lstore(cur ^ 1);
-        __syncthreads();
+        if (more && !Y3_ABL(2)) lstore(cur ^ 1);
+        if (!Y3_ABL(4)) __syncthreads();
         cur ^= 1;
     }
+    }
 
-    if (p.slab) {
-        // split-K: raw partial sums; bias / activation / statistics are applied by splitk_epilogue_kernel
-        float* out = p.slab + (long long)kz * p.M * p.Nout;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int n = n0 + wn * TN + j * 32 + l31;
+    Y3_TSTAMP(2);
+    if (nz > 1) {
+        // park the raw accumulators: slab[item][r4][thread] as 16-byte stores, one KiB per wave instruction.  The hand-off to the
+        // slice that finishes last follows MI355X_MICROARCH.md (workgroup dispatch, measured hand-offs, row 1): every byte is
+        // stored sc1 (written through, no L2 write-back fence needed) and loaded sc1, every storing wave drains vmcnt before the
+        // workgroup barrier, ONE lane then adds to the tile's ticket with an agent-scope atomic and the workgroup whose add
+        // came last (told by the value returned) loads after a second barrier.
+        constexpr int R4 = MB * NB * 4;
+        const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, 0x7ffffff0, 0x00020000);
+        const unsigned item_bytes = (unsigned)(R4 * THREADS * 16);
+        {
+            const unsigned base = (unsigned)(bid0 - p.sk_slab0) * item_bytes + (unsigned)tid * 16u;
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < p.M && n < p.Nout) out[(long long)m * p.Nout + n] = acc[i][j][r];
-                }
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        f32x4 v = {acc[i][j][4 * r], acc[i][j][4 * r + 1], acc[i][j][4 * r + 2], acc[i][j][4 * r + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, base, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
+                    }
         }
-        return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(&red[0][0][0]);
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(p.tickets + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == nz - 1;
+            if (last) __hip_atomic_store(p.tickets + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+        __syncthreads();  // `red` is reused by the statistics below
+        const unsigned first = (unsigned)(bid0 - kz - p.sk_slab0) * item_bytes + (unsigned)tid * 16u;   // slice 0 of this tile
+#pragma unroll 1
+        for (int z = 0; z < nz; ++z) {
+            const unsigned base = first + (unsigned)z * item_bytes;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, base, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * r + e] = z == 0 ? v[e] : acc[i][j][4 * r + e] + v[e];
+                    }
+        }
     }
 
     // ---- epilogue (same contract as conv_igemm_kernel)
@@ -547,11 +857,17 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int bid0
             if (n < p.Nout) p.stats[((long long)bm * 2 + which) * p.Nout + n] = s;
         }
     }
+#ifdef Y3_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (y3_timing_buf && threadIdx.x == 0) y3_timing_buf[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
+    Y3_TSTAMP(3);
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool DENSE>
+template <int BM, int BN, int WM, int WN, int BK, bool DENSE, int PIPE>
 __global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_kernel(const FastArgs p) {
-    conv_fast_body<BM, BN, WM, WN, BK, DENSE>(p, y3_xcd_remap(blockIdx.x, gridDim.x));
+    const int b = blockIdx.x;
+    conv_fast_body<BM, BN, WM, WN, BK, DENSE, PIPE>(p, b < p.sk_n0 ? y3_xcd_remap(b, p.sk_n0) : p.sk_n0 + y3_xcd_remap(b - p.sk_n0, (int)gridDim.x - p.sk_n0));
 }
 
 // Up to four independent gather-GEMMs in ONE launch: the (row parity, column parity) classes of a stride-2 data gradient.
@@ -569,84 +885,10 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_multi_kernel(
     conv_fast_body<BM, BN, WM, WN, BK, false>(m.a[c], y3_xcd_remap((int)blockIdx.x - m.first[c], m.first[c + 1] - m.first[c]));
 }
 
-// Split-K combine + the conv epilogue: v = sum_z slab[z][m][n] + bias -> lrelu -> stats -> affine -> + resid -> (+)= dst.
-// One block = 32 rows x Nout columns (float4 per thread along n); per-block partial statistics like the conv kernel's.
-#define Y3_SK_ROWS 32
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const FastArgs p) {
-    __shared__ float red[2][256 * 4];
-    const int c4n = p.Nout >> 2;
-    const int cw = c4n < 256 ? c4n : 256;
-    const int lanes = 256 / cw;
-    const int cq = threadIdx.x % cw, rl = threadIdx.x / cw;
-    const int r0 = blockIdx.x * Y3_SK_ROWS;
-    const int ohw = p.OH * p.OW;
-    const bool do_lrelu = p.flags & Y3_EPI_LRELU;
-    const bool do_accum = p.flags & Y3_EPI_ACCUM;
-    const bool dense = p.dsh == 1 && p.dsw == 1 && p.doh == 0 && p.dow == 0 && p.DH == p.OH && p.DW == p.OW;
-    const long long slab_stride = (long long)p.M * p.Nout;
-    for (int c4 = cq; c4 < c4n; c4 += cw) {
-        const int n = c4 * 4;
-        f32x4 bias = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
-        if (p.scale) {
-            sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-            sf = *reinterpret_cast<const f32x4*>(p.shift + n);
-        }
-        f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
-        if (rl < lanes)
-            for (int r = rl; r < Y3_SK_ROWS; r += lanes) {
-                const int m = r0 + r;
-                if (m >= p.M) break;
-                const float* s = p.slab + (long long)m * p.Nout + n;
-                f32x4 v = *reinterpret_cast<const f32x4*>(s);
-                for (int z = 1; z < p.ksplit; ++z) v += *reinterpret_cast<const f32x4*>(s + z * slab_stride);
-                v += bias;
-                if (do_lrelu)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : p.alpha * v[e];
-                ssum += v;
-                ssq += v * v;
-                long long pix;
-                if (dense) {
-                    pix = m;
-                } else {
-                    const int nimg = m / ohw;
-                    const int rr = m - nimg * ohw;
-                    const int oh = rr / p.OW;
-                    const int ow = rr - oh * p.OW;
-                    pix = ((long long)nimg * p.DH + oh * p.dsh + p.doh) * p.DW + ow * p.dsw + p.dow;
-                }
-                if (p.scale) v = v * sc + sf;
-                if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + pix * p.resid_ld + n);
-                float* d = p.dst + pix * p.dst_ld + n;
-                if (do_accum) v += *reinterpret_cast<const f32x4*>(d);
-                *reinterpret_cast<f32x4*>(d) = v;
-            }
-        if (p.stats) {
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                red[0][threadIdx.x * 4 + e] = ssum[e];
-                red[1][threadIdx.x * 4 + e] = ssq[e];
-            }
-            __syncthreads();
-            if (rl == 0) {
-                for (int g = 1; g < lanes; ++g)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ssum[e] += red[0][(g * cw + cq) * 4 + e];
-                        ssq[e] += red[1][(g * cw + cq) * 4 + e];
-                    }
-                *reinterpret_cast<f32x4*>(p.stats + ((long long)blockIdx.x * 2 + 0) * p.Nout + n) = ssum;
-                *reinterpret_cast<f32x4*>(p.stats + ((long long)blockIdx.x * 2 + 1) * p.Nout + n) = ssq;
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
 // kernel gradient: out[z][k][n] = sum_{m in chunk z} A[m][k] * ddst[m][n]
 // ---------------------------------------------------------------------------
+#define Y3_WG_FANIN 8   // kernel-gradient slab reduction: fan-in of the in-kernel tree
 struct WgradArgs {
     const float* src;
     const float* ddst;
@@ -657,8 +899,12 @@ struct WgradArgs {
     int dd_ld, Nout, K, M;
     int chunk;  // pixels per split (multiple of BP)
     int nbn, tiles, splits;
+    unsigned src_bytes, dd_bytes;  // extents for the buffer descriptors (out-of-range lanes read zeros)
+    int* tickets;  // splits > 1: one per (k-tile, n-tile), zero before the launch; `out` is then the slab area
+    float* dw;     // final destination [K][Nout]
 };
 
+#define Y3_WG_TABLE 2048   // pixels per split the LDS pixel table holds (plan_wgrad keeps chunks below it)
 template <int BKR, int BN, int WM, int WN, int BP>
 __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(const WgradArgs p) {
     constexpr int THREADS = 64 * WM * WN;
@@ -666,12 +912,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(const WgradArg
     constexpr int KR4 = BKR / 4, BN4 = BN / 4;
     constexpr int A_TOTAL = BP * KR4, A_LOADS = (A_TOTAL + THREADS - 1) / THREADS;
     constexpr int B_TOTAL = BP * BN4, B_LOADS = (B_TOTAL + THREADS - 1) / THREADS;
-    static_assert(THREADS % KR4 == 0 && THREADS % BN4 == 0, "loader shape");
+    static_assert(THREADS % KR4 == 0 && THREADS % BN4 == 0 && BP == 16, "loader shape");
     constexpr int A_PSTEP = THREADS / KR4;  // pixel distance between a thread's consecutive A loads
     constexpr int B_PSTEP = THREADS / BN4;
 
     __shared__ __attribute__((aligned(16))) float At[2][BP * BKR];
     __shared__ __attribute__((aligned(16))) float Bt[2][BP * BN];
+    __shared__ uint2 pix[Y3_WG_TABLE];   // per pixel of this split: {byte offset of its (dh, dw) = (0, 0) source pixel, tap validity bits}
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -694,80 +941,82 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(const WgradArg
     const int k0 = bk * BKR, n0 = bn * BN;
     const int mbeg = split * p.chunk;
     const int mend = min(p.M, mbeg + p.chunk);
+    const int nsteps = (mend > mbeg) ? (mend - mbeg + BP - 1) / BP : 0;
 
+    // Pixel table: the (image, row, column) decomposition of every pixel of the split and the zero-padding test of every
+    // tap are done ONCE here; the K loop then only reads {offset, mask} from LDS one step ahead.  Loads are buffer loads
+    // whose per-lane offset points past the descriptor's range whenever the element does not exist (padding, pixels beyond
+    // the split, K / Nout tails): the hardware returns zeros, the loop has no branches and no 64-bit address arithmetic.
+    {
+        const int ohw = p.OH * p.OW;
+        const int ntaps = p.K >> (p.logC > 30 ? 30 : p.logC) > 0 ? (p.logC > 30 ? 1 : p.K >> p.logC) : 1;
+        for (int pl = tid; pl < nsteps * BP; pl += THREADS) {
+            const int m = mbeg + pl;
+            unsigned off = 0, msk = 0;
+            if (m < mend) {
+                const int n = m / ohw;
+                const int r = m - n * ohw;
+                const int oh = r / p.OW, ow = r - oh * p.OW;
+                const int ih0 = oh * p.sh, iw0 = ow * p.sw;
+                off = (unsigned)(((n * p.H + ih0) * p.W + iw0) * p.src_ld) * 4u;
+                for (int t = 0; t < ntaps; ++t) {
+                    const int code = (int)((p.tap_dhdw >> (4 * t)) & 15ull);
+                    const int ih = ih0 + (code & 3) - 1, iw = iw0 + (code >> 2) - 1;
+                    if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) msk |= 1u << t;
+                }
+            }
+            pix[pl] = make_uint2(off, msk);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ddst), 0, p.dd_bytes, 0x00020000);
     // A: this thread always loads the same 4 k's (tap, c..c+3); only the pixel advances
     const int a_kv = tid % KR4;
     const int ak = k0 + a_kv * 4;
-    const bool ak_ok = ak < p.K;
+    const bool ak_ok = ak < p.K;            // K % 4 == 0 (Cin % 4 == 0): a quad is inside K or outside as a whole
     const int atap = ak_ok ? (ak >> p.logC) : 0;
     const int ac = ak & p.cmask;
     const int acode = (int)((p.tap_dhdw >> (4 * atap)) & 15ull);
-    const int adh = (acode & 3) - 1, adw = (acode >> 2) - 1;
-    int a_n[A_LOADS], a_oh[A_LOADS], a_ow[A_LOADS], a_m[A_LOADS];
-    const int ohw = p.OH * p.OW;
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-        const int pp = tid / KR4 + i * A_PSTEP;
-        const int m = mbeg + pp;
-        a_m[i] = m;
-        const int n = m / ohw;
-        const int r = m - n * ohw;
-        a_n[i] = n;
-        a_oh[i] = r / p.OW;
-        a_ow[i] = r - a_oh[i] * p.OW;
-    }
+    const int a_tapoff = ((((acode & 3) - 1) * p.W + ((acode >> 2) - 1)) * p.src_ld + ac) * 4;   // may be negative; only used where the tap is valid
+    const unsigned a_bit = ak_ok ? 1u << atap : 0u;
+    const int a_pp0 = tid / KR4;
     const int b_n4 = tid % BN4;
     const int bnn = n0 + b_n4 * 4;
     const bool bn_ok = bnn < p.Nout;
+    const int b_pp0 = tid / BN4;
+    const unsigned b_lane = (unsigned)(bnn * 4);
 
-    float4 ra[A_LOADS], rb[B_LOADS];
-    auto gload = [&](int step) {
+    f32x4 ra[A_LOADS], rb[B_LOADS];
+    uint2 pe[A_LOADS];                     // table entries of the step whose loads are issued next
+    auto tload = [&](int step) {          // LDS read of the table entries for `step`
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const int pp = tid / KR4 + i * A_PSTEP;
-            const int ih = a_oh[i] * p.sh + adh, iw = a_ow[i] * p.sw + adw;
-            const bool ok = ak_ok && pp < BP && a_m[i] < mend && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                v = *reinterpret_cast<const float4*>(p.src + (((long long)a_n[i] * p.H + ih) * p.W + iw) * p.src_ld + ac);
-                if (ak + 4 > p.K) {
-                    if (ak + 1 >= p.K) v.y = 0.f;
-                    if (ak + 2 >= p.K) v.z = 0.f;
-                    if (ak + 3 >= p.K) v.w = 0.f;
-                }
-            }
-            ra[i] = v;
-            // advance this slot's pixel by BP for the next step
-            a_m[i] += BP;
-            a_ow[i] += BP;
-            while (a_ow[i] >= p.OW) {
-                a_ow[i] -= p.OW;
-                if (++a_oh[i] == p.OH) {
-                    a_oh[i] = 0;
-                    ++a_n[i];
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) {
-            const int pp = tid / BN4 + i * B_PSTEP;
-            const int m = mbeg + step * BP + pp;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pp < BP && m < mend && bn_ok) v = *reinterpret_cast<const float4*>(p.ddst + (long long)m * p.dd_ld + bnn);
-            rb[i] = v;
+            const int pp = a_pp0 + i * A_PSTEP;
+            pe[i] = pix[step * BP + (A_TOTAL % THREADS == 0 || pp < BP ? pp : 0)];
         }
     };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) {
-            const int pp = tid / KR4 + i * A_PSTEP;
-            if (pp < BP) *reinterpret_cast<float4*>(&At[buf][pp * BKR + a_kv * 4]) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) {
-            const int pp = tid / BN4 + i * B_PSTEP;
-            if (pp < BP) *reinterpret_cast<float4*>(&Bt[buf][pp * BN + b_n4 * 4]) = rb[i];
-        }
+    auto gload_a = [&](int i) {
+        const int pp = a_pp0 + i * A_PSTEP;
+        const bool ok = ((pe[i].y & a_bit) != 0) & (A_TOTAL % THREADS == 0 || pp < BP);
+        const unsigned off = pe[i].x + (unsigned)a_tapoff;
+        const unsigned vo = ok ? off : Y3_OOB;
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, vo, 0, 0);
+    };
+    auto gload_b = [&](int i, int step) {
+        const int pp = b_pp0 + i * B_PSTEP;
+        const int m = mbeg + step * BP + pp;
+        const unsigned off = (unsigned)(m * p.dd_ld) * 4u + b_lane;      // unconditional arithmetic + select: no divergent branch in the loop
+        const bool ok = (B_TOTAL % THREADS == 0 || pp < BP) & (m < mend) & bn_ok;
+        const unsigned vo = ok ? off : Y3_OOB;
+        rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dd, vo, 0, 0);
+    };
+    auto lstore_a = [&](int i, int buf) {
+        const int pp = a_pp0 + i * A_PSTEP;
+        if (A_TOTAL % THREADS == 0 || pp < BP) *reinterpret_cast<f32x4*>(&At[buf][pp * BKR + a_kv * 4]) = ra[i];
+    };
+    auto lstore_b = [&](int i, int buf) {
+        const int pp = b_pp0 + i * B_PSTEP;
+        if (B_TOTAL % THREADS == 0 || pp < BP) *reinterpret_cast<f32x4*>(&Bt[buf][pp * BN + b_n4 * 4]) = rb[i];
     };
 
     f32x16 acc[MB][NB];
@@ -778,36 +1027,172 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(const WgradArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nsteps = (mend > mbeg) ? (mend - mbeg + BP - 1) / BP : 0;
-    if (nsteps > 0) {
-        gload(0);
-        lstore(0);
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int st = 0; st < nsteps; ++st) {
-        const bool more = st + 1 < nsteps;
-        if (more) gload(st + 1);
-        const float* as = &At[cur][lh * BKR + wm * TM + l31];
-        const float* bs = &Bt[cur][lh * BN + wn * TN + l31];
+    // Same hand-interleaved software pipeline as conv_fast_body (PIPE 2): a step is BP = 16 pixels = two groups of four
+    // pixel pairs; every MFMA is followed by a slot with at most a couple of memory instructions.
+    //   group 0: LDS reads of fragment set 1 (pairs 4..7 of this buffer), then the LDS stores of the next step's tile
+    //   LDS-only barrier
+    //   group 1: global loads for the step after next (table entries were read a step ahead), the table entries of the step
+    //            after that, then the LDS reads of set 0 from the next buffer
+    constexpr int GP = 4;
+    constexpr int NM = GP * MB * NB;
+    constexpr int NW = A_LOADS + B_LOADS;
+    constexpr int NE = GP + NW + 1;      // events per half: 4 fragment-pair reads + NW stores / loads (+ the table read in group 1)
+    float fa[2][GP][MB], fb[2][GP][NB];
+    const float* as_base = &At[0][lh * BKR + wm * TM + l31];
+    const float* bs_base = &Bt[0][lh * BN + wn * TN + l31];
+    auto ldf_pair = [&](int buf, int g, int u, int set) {
 #pragma unroll
-        for (int pp = 0; pp < BP / 2; ++pp) {
-            float av[MB], bv[NB];
+        for (int i = 0; i < MB; ++i) fa[set][u][i] = as_base[buf * (BP * BKR) + (g * GP + u) * 2 * BKR + i * 32];
 #pragma unroll
-            for (int i = 0; i < MB; ++i) av[i] = as[pp * 2 * BKR + i * 32];
-#pragma unroll
-            for (int j = 0; j < NB; ++j) bv[j] = bs[pp * 2 * BN + j * 32];
-#pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NB; ++j) fb[set][u][j] = bs_base[buf * (BP * BN) + (g * GP + u) * 2 * BN + j * 32];
+    };
+    auto event = [&](auto G, auto E, auto H1, auto H2, int cur, int st) {
+        constexpr int g = decltype(G)::value, e = decltype(E)::value;
+        constexpr bool h1 = decltype(H1)::value, h2 = decltype(H2)::value;
+        if constexpr (g == 0) {
+            if constexpr (e < GP) {
+                ldf_pair(cur, 1, e, 1);
+            } else if constexpr (e < GP + NW) {
+                if constexpr (h1) {
+                    constexpr int w = e - GP;
+                    if constexpr (w < A_LOADS)
+                        lstore_a(w, cur ^ 1);
+                    else
+                        lstore_b(w - A_LOADS, cur ^ 1);
+                }
+            }
+        } else {
+            if constexpr (e < NW) {
+                if constexpr (h2) {
+                    if constexpr (e < A_LOADS)
+                        gload_a(e);
+                    else
+                        gload_b(e - A_LOADS, st + 2);
+                }
+            } else if constexpr (e == NW) {
+                if constexpr (h2) tload(min(st + 3, nsteps - 1));
+            } else if constexpr (h1) {
+                ldf_pair(cur ^ 1, 0, e - NW - 1, 0);
+            }
         }
-        if (more) lstore(cur ^ 1);
+    };
+    auto half = [&](auto G, auto H1, auto H2, int cur, int st) {
+        constexpr int g = decltype(G)::value;
+        y3_for_each_ic(std::make_integer_sequence<int, NM>{}, [&](auto Mi) {
+            constexpr int m = decltype(Mi)::value;
+            constexpr int u = m / (MB * NB), i = (m / NB) % MB, j = m % NB;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][u][i], fb[g][u][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int e0 = NE <= NM ? m : m * NE / NM, e1 = NE <= NM ? (m < NE ? m + 1 : m) : (m + 1) * NE / NM;
+            y3_for_each_ic(std::make_integer_sequence<int, e1 - e0>{}, [&](auto D) { event(G, std::integral_constant<int, e0 + decltype(D)::value>{}, H1, H2, cur, st); });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto step = [&](auto H1, auto H2, int st) {
+        const int cur = st & 1;
+        half(std::integral_constant<int, 0>{}, H1, H2, cur, st);
+        if constexpr (decltype(H1)::value) y3_lds_barrier();
+        half(std::integral_constant<int, 1>{}, H1, H2, cur, st);
+    };
+    __syncthreads();                       // pixel table complete
+    if (nsteps > 0) {
+        tload(0);
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) gload_a(i);
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) gload_b(i, 0);
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) lstore_a(i, 0);
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) lstore_b(i, 0);
         __syncthreads();
-        cur ^= 1;
+        if (nsteps > 1) {
+            tload(1);
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) gload_a(i);
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) gload_b(i, 1);
+        }
+        tload(min(2, nsteps - 1));
+#pragma unroll
+        for (int u = 0; u < GP; ++u) ldf_pair(0, 0, u, 0);
+        int st = 0;
+        for (; st + 2 < nsteps; ++st) step(std::true_type{}, std::true_type{}, st);
+        if (st + 1 < nsteps) {
+            step(std::true_type{}, std::false_type{}, st);
+            ++st;
+        }
+        step(std::false_type{}, std::false_type{}, st);
+    }
+    __syncthreads();                       // (the reduction below reuses At as a flag word)
+
+    if (p.splits > 1 && p.tickets != nullptr) {
+        // Reduction over the pixel splits inside the kernel, as a fixed tree of fan-in Y3_WG_FANIN (bit-reproducible: the
+        // shape of the tree depends on the launch geometry only).  Level by level: park the raw accumulators
+        // (slab[level][tile][index][r4][thread], 16-byte sc1 stores), take the ticket of the group of FANIN neighbours; the
+        // member that draws the group's last ticket sums the group's slabs in index order and carries the sum to the next
+        // level; the others leave.  A flat "last split sums everything" reduction serialises up to ~1 000 slab reads in one
+        // workgroup (measured: kernel gradients 2x slower).  Hand-off rules: see conv_fast_body.
+        constexpr int R4 = MB * NB * 4;
+        const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x7ffffff0, 0x00020000);
+        const unsigned item_bytes = (unsigned)(R4 * THREADS * 16);
+        int* flag = reinterpret_cast<int*>(&At[0][0]);
+        int idx = split, count = p.splits;
+        unsigned slab_base = 0;     // items before this level
+        int ticket_base = 0;
+        while (count > 1) {
+            const int groups = (count + Y3_WG_FANIN - 1) / Y3_WG_FANIN;
+            const int group = idx / Y3_WG_FANIN;
+            const int gsize = min(Y3_WG_FANIN, count - group * Y3_WG_FANIN);
+            const unsigned level0 = (slab_base + (unsigned)(bid * count)) * item_bytes + (unsigned)tid * 16u;
+            if (gsize > 1) {
+                const unsigned base = level0 + (unsigned)idx * item_bytes;
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            f32x4 v = {acc[i][j][4 * r], acc[i][j][4 * r + 1], acc[i][j][4 * r + 2], acc[i][j][4 * r + 3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, base, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
+                        }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    int* tk = p.tickets + ticket_base + bid * groups + group;
+                    const int old = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int last = old == gsize - 1;
+                    if (last) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *flag = last;
+                }
+                __syncthreads();
+                const int last = *flag;
+                __syncthreads();          // the flag word is rewritten at the next level
+                if (!last) return;
+#pragma unroll 1
+                for (int z = 0; z < gsize; ++z) {
+                    const unsigned base2 = level0 + (unsigned)(group * Y3_WG_FANIN + z) * item_bytes;
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, base2, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[i][j][4 * r + e] = z == 0 ? v[e] : acc[i][j][4 * r + e] + v[e];
+                            }
+                }
+            }
+            slab_base += (unsigned)(p.tiles * count);
+            ticket_base += p.tiles * groups;
+            idx = group;
+            count = groups;
+        }
     }
 
-    float* out = p.out + (long long)split * p.K * p.Nout;
+    // no tickets: `out` is dw itself (one split) or the split's slab in the natural [K][Nout] layout (slab_reduce_kernel follows)
+    float* out = p.tickets != nullptr ? p.dw : p.out + (p.splits > 1 ? (long long)split * p.K * p.Nout : 0ll);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int n = n0 + wn * TN + j * 32 + l31;
@@ -823,7 +1208,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(const WgradArg
 
 // dst[i] = sum_z slabs[z][i], fixed summation order (deterministic).  A block owns 64 consecutive outputs
 // (16 float4 lanes) x 16 slab lanes: the slab axis is parallel too, so a few-thousand-element gradient
-// split over ~1000 pixel chunks is not reduced by a handful of serial threads.
+// split over ~1000 pixel chunks is not reduced by a handful of serial threads.  Used when a kernel gradient has more
+// splits than the in-kernel reduction handles in one level (Y3_WG_FANIN): there the whole chip streams the slabs.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dst, long long count, int nslabs) {
     __shared__ f32x4 sm[16][16];
     const int cl = threadIdx.x & 15, zl = threadIdx.x >> 4;
@@ -946,37 +1332,72 @@ static TileCfg pick_tile(int M, int Nout) {
     return t;
 }
 
+#define Y3_WS_HEADER (256 * 1024)   // bytes of tile tickets in front of the slabs (65 536 tiles)
+#define Y3_MAX_TICKETS (Y3_WS_HEADER / 4)
 struct ConvPlan {
     TileCfg t;
-    int ksplit, kchunk, stats_tiles;
+    int f, s0, s1, chunk0, chunk1;   // FastArgs::sk_*: tiles [0,f) in s0 slices of chunk0 K steps, the rest in s1 of chunk1
+    int tiles, stats_tiles;
     size_t ws_bytes;
 };
 // fast_ok: the launch qualifies for conv_igemm_fast_kernel (the only kernel with split-K)
 static ConvPlan plan_conv(int M, int Nout, int K, bool fast_ok) {
     ConvPlan pl;
     pl.t = pick_tile(M, Nout);
-    pl.ksplit = 1;
-    pl.kchunk = K;
-    const long long tiles = (long long)y3_cdiv(M, pl.t.bm) * y3_cdiv(Nout, pl.t.bn);
+    const int tiles = y3_cdiv(M, pl.t.bm) * y3_cdiv(Nout, pl.t.bn);
+    const int nk = K / pl.t.bk;                                   // K steps (fast path: K % bk == 0)
+    pl.tiles = tiles;
+    pl.f = tiles;
+    pl.s0 = pl.s1 = 1;
+    pl.chunk0 = pl.chunk1 = nk > 0 ? nk : 1;
     static const int want = env_int("Y3_SPLITK_WGS", 1400);   // workgroups to aim for
     static const int min_k = env_int("Y3_SPLITK_MINK", 256);  // shortest K slice worth a launch
+    static const int cus = env_int("Y3_CUS", 256);
+    static const int rsplit_on = env_int("Y3_RSPLIT", 1);
     // measured (tools/fixed_cost.py, layer_times.py): a 676-tile launch (2.6 workgroups per CU) is better left whole unless
     // K is long; at <= 512 tiles the extra workgroups win over the slab round trip
-    const bool few_tiles = tiles <= 512 || (tiles * 2 <= want && K >= 2048);
-    if (fast_ok && Nout <= 1024 && few_tiles && K >= 2 * min_k) {
+    const bool few_tiles = tiles <= 512 || ((long long)tiles * 2 <= want && K >= 2048);
+    if (fast_ok && tiles <= Y3_MAX_TICKETS && few_tiles && K >= 2 * min_k) {
         int ks = (int)((want + tiles / 2) / tiles);
         const int maxs = K / min_k;
         if (ks > maxs) ks = maxs;
         if (ks > 16) ks = 16;
         if (ks > 1) {
-            int chunk = y3_cdiv(K, ks);
-            chunk = y3_cdiv(chunk, pl.t.bk) * pl.t.bk;
-            pl.ksplit = y3_cdiv(K, chunk);
-            pl.kchunk = chunk;
+            pl.chunk0 = y3_cdiv(nk, ks);
+            pl.s0 = y3_cdiv(nk, pl.chunk0);
+        }
+    } else if (fast_ok && rsplit_on && tiles <= Y3_MAX_TICKETS && tiles > cus && nk >= 8) {
+        // whole rounds of tiles stay whole; the remainder round is cut along K so that its pieces spread evenly over the CUs:
+        // load per CU = full rounds + ceil(R * S / CUs) / S tiles against tiles / CUs ideal
+        const int F = tiles / cus * cus, R = tiles - F;
+        if (R > 0) {
+            int best = 1;
+            double best_cost = 1.0;
+            for (int S = 2; S <= 6 && S * 4 <= nk; ++S) {
+                const double cost = (double)y3_cdiv((long long)R * S, cus) / S + 0.03 * (S - 1);
+                if (cost < best_cost - 1e-9) {
+                    best_cost = cost;
+                    best = S;
+                }
+            }
+            if (best > 1) {
+                pl.f = F;
+                pl.chunk1 = y3_cdiv(nk, best);
+                pl.s1 = y3_cdiv(nk, pl.chunk1);
+            }
         }
     }
-    pl.stats_tiles = pl.ksplit > 1 ? y3_cdiv(M, Y3_SK_ROWS) : y3_cdiv(M, pl.t.bm);
-    pl.ws_bytes = pl.ksplit > 1 ? (size_t)pl.ksplit * M * Nout * sizeof(float) : 0;
+    pl.stats_tiles = y3_cdiv(M, pl.t.bm);
+    const long long split_items = pl.s0 > 1 ? (long long)pl.f * pl.s0 + (long long)(tiles - pl.f) * pl.s1 : (pl.s1 > 1 ? (long long)(tiles - pl.f) * pl.s1 : 0);
+    const long long slab_bytes = split_items * pl.t.bm * pl.t.bn * 4;
+    if (slab_bytes >= 0x7ff00000LL) {   // slab offsets are 32-bit buffer offsets: fall back to whole tiles
+        pl.f = tiles;
+        pl.s0 = pl.s1 = 1;
+        pl.chunk0 = pl.chunk1 = nk > 0 ? nk : 1;
+        pl.ws_bytes = 0;
+    } else {
+        pl.ws_bytes = split_items > 0 ? (size_t)Y3_WS_HEADER + (size_t)slab_bytes : 0;
+    }
     return pl;
 }
 static bool fast_shape_ok(int C, int Nout, int K, int ntaps) {
@@ -998,10 +1419,24 @@ static void launch_cfg(const ConvArgs& p, int grid, hipStream_t st) {
 }
 template <int BM, int BN, int WM, int WN, int BK>
 static void launch_fast(const FastArgs& p, bool dense, int grid, hipStream_t st) {
-    if (dense)
-        hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, true>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
-    else
-        hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, false>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
+    static const int pipe = env_int("Y3_PIPE", 2);
+    const dim3 g(grid), b(64 * WM * WN);
+    if (pipe == 2) {
+        if (dense)
+            hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, true, 2>), g, b, 0, st, p);
+        else
+            hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, false, 2>), g, b, 0, st, p);
+    } else if (pipe == 1) {
+        if (dense)
+            hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, true, 1>), g, b, 0, st, p);
+        else
+            hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, false, 1>), g, b, 0, st, p);
+    } else {
+        if (dense)
+            hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, true, 0>), g, b, 0, st, p);
+        else
+            hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, false, 0>), g, b, 0, st, p);
+    }
 }
 
 // Build the fast kernel's arguments; false if the launch does not qualify.
@@ -1035,6 +1470,24 @@ static bool make_fast(const ConvArgs& a, int ntaps, int bk, FastArgs* f) {
         p.tap_wrow[t] = (int)((a.tap_wsel >> (4 * t)) & 15ull) * a.C;
     }
     p.ntaps = ntaps;
+    {
+        // the tap list as a (rows x nx) grid: nx = length of the first run of equal dh
+        int nx = 1;
+        while (nx < ntaps && dh[nx] == dh[0]) ++nx;
+        if (ntaps % nx != 0) return false;
+        p.tg_nx = nx;
+        p.tg_off0 = p.tap_off[0];
+        p.tg_w0 = p.tap_wrow[0];
+        p.tg_offx = nx > 1 ? p.tap_off[1] - p.tap_off[0] : 0;
+        p.tg_wx = nx > 1 ? p.tap_wrow[1] - p.tap_wrow[0] : 0;
+        p.tg_offy = ntaps > nx ? p.tap_off[nx] - p.tap_off[0] : 0;
+        p.tg_wy = ntaps > nx ? p.tap_wrow[nx] - p.tap_wrow[0] : 0;
+        if (nx > 3) return false;
+        for (int t = 0; t < ntaps; ++t)
+            if (p.tap_off[t] != p.tg_off0 + (t / nx) * p.tg_offy + (t % nx) * p.tg_offx ||
+                p.tap_wrow[t] != p.tg_w0 + (t / nx) * p.tg_wy + (t % nx) * p.tg_wx)
+                return false;   // not a grid: the generic kernel takes it
+    }
     {
         const long long dpix = a.dense_dst ? (long long)a.M : (long long)a.src_n * a.DH * a.DW;
         const long long db = dpix * a.dst_ld * 4, rb = dpix * (long long)a.resid_ld * 4;
@@ -1079,13 +1532,11 @@ static int launch_igemm(const ConvArgs& a, void* workspace, size_t workspace_byt
     const int ntaps = p.K / p.C;
     const bool fast_ok = fast_shape_ok(p.C, p.Nout, p.K, ntaps);
     ConvPlan pl = plan_conv(p.M, p.Nout, p.K, fast_ok);
-    if (pl.ksplit > 1 && (workspace == nullptr || workspace_bytes < pl.ws_bytes)) {  // no room for slabs: single pass
-        pl.ksplit = 1;
-        pl.kchunk = p.K;
-        if (p.stats) {
-            y3_set_error("conv: workspace %zu < %zu needed by the planned split-K launch", workspace_bytes, pl.ws_bytes);
-            return Y3_EINVAL;  // the caller sized `stats` for the split-K plan
-        }
+    if (pl.ws_bytes > 0 && (workspace == nullptr || workspace_bytes < pl.ws_bytes)) {  // no room for slabs: whole tiles
+        pl.f = pl.tiles;
+        pl.s0 = pl.s1 = 1;
+        pl.chunk0 = pl.chunk1 = p.K / pl.t.bk;
+        pl.ws_bytes = 0;
     }
     const TileCfg t = pl.t;
     p.nbn = y3_cdiv(p.Nout, t.bn);
@@ -1094,10 +1545,18 @@ static int launch_igemm(const ConvArgs& a, void* workspace, size_t workspace_byt
     FastArgs f;
     if (fast_ok && make_fast(p, ntaps, t.bk, &f)) {
         f.nbn = p.nbn;
-        f.ksplit = pl.ksplit;
-        f.kchunk = pl.kchunk;
-        f.slab = pl.ksplit > 1 ? (float*)workspace : nullptr;
-        const int grid = tiles * pl.ksplit;
+        f.sk_f = pl.f;
+        f.sk_s0 = pl.s0;
+        f.sk_s1 = pl.s1;
+        f.sk_n0 = pl.f * pl.s0;
+        f.sk_chunk0 = pl.chunk0;
+        f.sk_chunk1 = pl.chunk1;
+        f.sk_slab0 = pl.s0 > 1 ? 0 : f.sk_n0;
+        f.tickets = pl.ws_bytes ? (int*)workspace : nullptr;
+        static const int stagger = env_int("Y3_STAGGER", 0);
+        f.stagger = stagger;
+        f.slab = pl.ws_bytes ? (float*)((char*)workspace + Y3_WS_HEADER) : nullptr;
+        const int grid = f.sk_n0 + (tiles - pl.f) * pl.s1;
         const bool dense = p.dense_dst != 0;
         switch (key) {
             case 128 * 10000 + 128 * 10 + 0: launch_fast<128, 128, 2, 2, 16>(f, dense, grid, st); break;
@@ -1115,10 +1574,6 @@ static int launch_igemm(const ConvArgs& a, void* workspace, size_t workspace_byt
             default: y3_set_error("conv: no fast kernel for tile %dx%dx%d", t.bm, t.bn, t.bk); return Y3_EINVAL;
         }
         Y3_CHECK_LAUNCH("conv_igemm_fast");
-        if (pl.ksplit > 1) {
-            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(y3_cdiv(p.M, Y3_SK_ROWS)), dim3(256), 0, st, f);
-            Y3_CHECK_LAUNCH("splitk_epilogue");
-        }
         return Y3_OK;
     }
     const int grid = tiles;
@@ -1243,9 +1698,13 @@ static bool launch_dgrad_multi(const ConvArgs* cls, int ncls, hipStream_t st) {
         const int ntaps = cls[c].K / cls[c].C;
         if (!fast_shape_ok(cls[c].C, cls[c].Nout, cls[c].K, ntaps) || !make_fast(cls[c], ntaps, t.bk, &m.a[c])) return false;
         m.a[c].nbn = y3_cdiv(cls[c].Nout, t.bn);
-        m.a[c].ksplit = 1;
-        m.a[c].kchunk = cls[c].K;
+        m.a[c].sk_f = m.a[c].sk_n0 = y3_cdiv(cls[c].M, t.bm) * m.a[c].nbn;   // whole tiles only
+        m.a[c].sk_s0 = m.a[c].sk_s1 = 1;
+        m.a[c].sk_chunk0 = m.a[c].sk_chunk1 = cls[c].K / t.bk;
+        m.a[c].sk_slab0 = 0;
         m.a[c].slab = nullptr;
+        m.a[c].tickets = nullptr;
+        m.a[c].stagger = 0;
         m.first[c] = first;
         first += y3_cdiv(cls[c].M, t.bm) * m.a[c].nbn;
     }
@@ -1379,6 +1838,7 @@ static WgradPlan plan_wgrad(int K, int Nout, int M) {
     const int maxs = y3_cdiv(M, 128);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
+    if (splits < y3_cdiv(M, Y3_WG_TABLE - 16)) splits = y3_cdiv(M, Y3_WG_TABLE - 16);   // a split's pixels fit the kernel's LDS pixel table
     int chunk = y3_cdiv(M, splits);
     chunk = y3_cdiv(chunk, 16) * 16;
     w.splits = y3_cdiv(M, chunk);
@@ -1386,12 +1846,25 @@ static WgradPlan plan_wgrad(int K, int Nout, int M) {
     return w;
 }
 
+// splits <= Y3_WG_FANIN: the reduction runs inside the kernel (one level: tickets + fragment-order slabs behind the header);
+// more splits: natural-layout slabs [split][K][Nout] + slab_reduce_kernel (measured: a multi-level in-kernel tree costs more
+// than the streaming reduce when every split is only a few K steps long)
+static bool wgrad_in_kernel(const WgradPlan& w) {
+    static const int mode = env_int("Y3_WGRAD_INKERNEL", 1);
+    return mode != 0 && w.splits > 1 && w.splits <= Y3_WG_FANIN && w.tiles <= Y3_MAX_TICKETS;
+}
+static size_t wgrad_ws_bytes(const WgradPlan& w, int K, int Nout) {
+    if (w.splits <= 1) return 0;
+    if (wgrad_in_kernel(w)) return (size_t)Y3_WS_HEADER + (size_t)w.tiles * w.splits * w.bkr * w.bn * sizeof(float);
+    return (size_t)Y3_WS_HEADER + (size_t)w.splits * K * Nout * sizeof(float);
+}
+
 extern "C" size_t y3_conv2d_wgrad_workspace(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride) {
     (void)stride;
     const int K = ksize * ksize * src->c;
     const int M = ddst->n * ddst->h * ddst->w;
     const WgradPlan w = plan_wgrad(K, ddst->c, M);
-    return w.splits > 1 ? (size_t)w.splits * K * ddst->c * sizeof(float) : 0;
+    return wgrad_ws_bytes(w, K, ddst->c);
 }
 
 extern "C" int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride, float* dw, void* workspace,
@@ -1426,12 +1899,22 @@ extern "C" int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int 
     p.Nout = ddst->c;
     p.K = taps * src->c;
     p.M = src->n * OH * OW;
+    {
+        const long long sb = (long long)src->n * src->h * src->w * src->ld * 4, db = (long long)p.M * ddst->ld * 4;
+        Y3_CHECK_ARG(sb < 0x7fffffffLL && db < 0x7fffffffLL, "conv2d_wgrad: tensors of 2 GiB or more are not supported (32-bit buffer offsets)");
+        p.src_bytes = (unsigned)sb;
+        p.dd_bytes = (unsigned)db;
+    }
     const WgradPlan w = plan_wgrad(p.K, p.Nout, p.M);
     p.chunk = w.chunk;
     p.nbn = y3_cdiv(p.Nout, w.bn);
-    const size_t need = w.splits > 1 ? (size_t)w.splits * p.K * p.Nout * sizeof(float) : 0;
+    const size_t need = wgrad_ws_bytes(w, p.K, p.Nout);
     Y3_CHECK_ARG(workspace_bytes >= need && (need == 0 || workspace), "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
-    p.out = w.splits > 1 ? (float*)workspace : dw;
+    Y3_CHECK_ARG(need < 0x7ff00000ull, "conv2d_wgrad: slab area too large (%zu bytes)", need);
+    const bool in_kernel = wgrad_in_kernel(w);
+    p.tickets = in_kernel ? (int*)workspace : nullptr;
+    p.out = w.splits > 1 ? (float*)((char*)workspace + Y3_WS_HEADER) : dw;
+    p.dw = dw;
     hipStream_t st = (hipStream_t)stream;
     p.tiles = w.tiles;
     p.splits = w.splits;
@@ -1449,9 +1932,9 @@ extern "C" int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int 
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<64, 32, 2, 1, 16>), grid, dim3(128), 0, st, p);
     Y3_CHECK_LAUNCH("conv_wgrad");
-    if (w.splits > 1) {
+    if (w.splits > 1 && !in_kernel) {
         const long long count = (long long)p.K * p.Nout;  // K*Nout is a multiple of 4 (Cin % 4 == 0)
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, st, (const float*)workspace, dw, count, w.splits);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, st, (const float*)p.out, dw, count, w.splits);
         Y3_CHECK_LAUNCH("slab_reduce");
     }
     return Y3_OK;

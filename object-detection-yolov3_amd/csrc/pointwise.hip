@@ -172,7 +172,8 @@ extern "C" int y3_bn_apply(const y3_tensor* a, const float* scale, const float* 
 // ---------------------------------------------------------------------------
 // BatchNorm + leaky-relu backward
 // ---------------------------------------------------------------------------
-#define Y3_BNB_MAXPARTS 512
+#define Y3_BNB_MAXPARTS 512           // 2 blocks per CU; more parts did not speed the reduce up and slow the finalize down (measured)
+#define Y3_BNB_SUMS 6
 extern "C" int y3_bn_bwd_partials(int m, int c) {
     if (c < 4 || c > 1024) return 1;
     const int rows_per_pass = 256 / (c / 4);
@@ -182,21 +183,24 @@ extern "C" int y3_bn_bwd_partials(int m, int c) {
     return parts;
 }
 
-// partials[part][5][C] (fp64): sum dy, sum dy*xhat, sum dy*s, sum s, sum xhat*s   (s = lrelu slope at a)
+// partials[part][6][C] (fp64), raw moments of (dy, a):
+//   S0 = sum dy, S1 = sum dy*a, S2 = sum_{a>0} dy, S3 = sum_{a>0} a, S4 = #{a>0}, S5 = sum a
+// The leaky-relu slope s is 1 for a > 0 and alpha otherwise, so with xhat = (a - mu) * r
+//   sum dy*xhat = r*(S1 - mu*S0),  sum dy*s = alpha*S0 + (1-alpha)*S2,  sum s = alpha*M + (1-alpha)*S4,
+//   sum xhat*s  = r*((1-alpha)*(S3 - mu*S4) + alpha*(S5 - mu*M))
+// (bn_bwd_finalize does that algebra in fp64).  Raw moments keep the per-element work at two conversions, one fma and a
+// few (masked) adds, and the kernel no longer needs the saved mean / rstd.
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int dy_ld, const float* __restrict__ a, int a_ld,
-                                                            const float* __restrict__ mean, const float* __restrict__ rstd, float alpha,
                                                             float* __restrict__ partials, long long npix, int C) {
     // fp64 accumulation: dbias is a small difference of these sums (BatchNorm removes the mean shift a
     // bias introduces), so fp32 running sums would lose it to cancellation
-    __shared__ double sm[256 * 20];
+    __shared__ double sm[256 * 4 * Y3_BNB_SUMS];
     const int c4n = C >> 2;
     const int rpp = 256 / c4n;
     const int cq = threadIdx.x % c4n, rg = threadIdx.x / c4n;
     const int c = cq * 4;
-    const float4 mu = *reinterpret_cast<const float4*>(mean + c);
-    const float4 rs = *reinterpret_cast<const float4*>(rstd + c);
-    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
     double acc[5][4];
+    int cnt[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 5; ++j)
 #pragma unroll
@@ -209,18 +213,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const double xh = ((double)av[e] - (double)muv[e]) * (double)rsv[e];
-            const double s = av[e] > 0.f ? 1.0 : (double)alpha;
-            const double d = (double)dv[e];
+            const double d = (double)dv[e], x = (double)av[e];
+            const bool pos = av[e] > 0.f;
             acc[0][e] += d;
-            acc[1][e] += d * xh;
-            acc[2][e] += d * s;
-            acc[3][e] += s;
-            acc[4][e] += xh * s;
+            acc[1][e] += d * x;
+            acc[2][e] += pos ? d : 0.0;
+            acc[3][e] += pos ? x : 0.0;
+            acc[4][e] += x;
+            cnt[e] += pos ? 1 : 0;
         }
     };
-    // four rows per trip: eight 16-byte loads in flight per thread (the kernel runs at 2 waves / SIMD); rows are still
-    // accumulated in their original order
+    // four rows per trip: eight 16-byte loads in flight per thread; rows are still accumulated in their original order
     long long r = r0 + rg;
     for (; r + 3LL * rpp < r1; r += 4LL * rpp) {
         float4 d4[4], a4[4];
@@ -234,54 +237,68 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
     for (; r < r1; r += rpp)
         accumulate(*reinterpret_cast<const float4*>(dy + r * dy_ld + c), *reinterpret_cast<const float4*>(a + r * a_ld + c));
+    // order in memory: S0, S1, S2, S3, S4 (count), S5 (sum a)
+    double out[Y3_BNB_SUMS][4];
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+    for (int e = 0; e < 4; ++e) {
+        out[0][e] = acc[0][e];
+        out[1][e] = acc[1][e];
+        out[2][e] = acc[2][e];
+        out[3][e] = acc[3][e];
+        out[4][e] = (double)cnt[e];
+        out[5][e] = acc[4][e];
+    }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sm[threadIdx.x * 20 + j * 4 + e] = acc[j][e];
+    for (int j = 0; j < Y3_BNB_SUMS; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sm[threadIdx.x * (4 * Y3_BNB_SUMS) + j * 4 + e] = out[j][e];
     __syncthreads();
     if (rg == 0) {
         for (int g = 1; g < rpp; ++g)
 #pragma unroll
-            for (int j = 0; j < 5; ++j)
+            for (int j = 0; j < Y3_BNB_SUMS; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[j][e] += sm[(g * c4n + cq) * 20 + j * 4 + e];
+                for (int e = 0; e < 4; ++e) out[j][e] += sm[(g * c4n + cq) * (4 * Y3_BNB_SUMS) + j * 4 + e];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            double* dst = reinterpret_cast<double*>(partials) + ((long long)blockIdx.x * 5 + j) * C + c;
-            dst[0] = acc[j][0];
-            dst[1] = acc[j][1];
-            dst[2] = acc[j][2];
-            dst[3] = acc[j][3];
+        for (int j = 0; j < Y3_BNB_SUMS; ++j) {
+            double* dst = reinterpret_cast<double*>(partials) + ((long long)blockIdx.x * Y3_BNB_SUMS + j) * C + c;
+            dst[0] = out[j][0];
+            dst[1] = out[j][1];
+            dst[2] = out[j][2];
+            dst[3] = out[j][3];
         }
     }
 }
 
 extern "C" int y3_bn_bwd_reduce(const y3_tensor* dy, const y3_tensor* a, const float* save_mean, const float* save_rstd, float alpha,
                                 float* partials, int* nparts, y3_stream_t stream) {
+    (void)save_mean;
+    (void)save_rstd;
+    (void)alpha;   // raw moments: mean / rstd / slope enter in y3_bn_bwd_finalize
     if (int e = check_view4(dy, "bn_bwd_reduce dy")) return e;
     if (int e = check_view4(a, "bn_bwd_reduce a")) return e;
-    Y3_CHECK_ARG(same_geom(dy, a) && save_mean && save_rstd && partials, "bn_bwd_reduce: geometry/pointers");
-    Y3_CHECK_ARG(a->c <= 1024 && 256 % (a->c / 4) == 0, "bn_bwd_reduce: channels %d unsupported", a->c);
+    Y3_CHECK_ARG(same_geom(dy, a) && partials, "bn_bwd_reduce: geometry/pointers");
+    Y3_CHECK_ARG(a->c <= 1024 && 256 % (a->c / 4) == 0, "bn_bwd_reduce: channels %d unsupported (C/4 must divide 256, C <= 1024)", a->c);
     const int parts = y3_bn_bwd_partials((int)pixels(a), a->c);
     if (nparts) *nparts = parts;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, dy->ptr, dy->ld, a->ptr, a->ld, save_mean,
-                       save_rstd, alpha, partials, pixels(a), a->c);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, dy->ptr, dy->ld, a->ptr, a->ld, partials, pixels(a),
+                       a->c);
     Y3_CHECK_LAUNCH("bn_bwd_reduce");
     return Y3_OK;
 }
 
-// A block owns 4 channels: 128 partial-row lanes x 5 sums = 640 threads, each loading 4 doubles per row; C/4 blocks.
-__global__ __launch_bounds__(640) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, double inv_count,
+// A block owns 4 channels: 128 partial-row lanes x 6 sums = 768 threads, each loading 4 doubles per row; C/4 blocks.
+__global__ __launch_bounds__(768) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, double count, float alpha,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, float* dgamma, float* dbeta,
                                                               float* dbias, float* coef) {
-    __shared__ double sm[5][128][4];
-    const int j = threadIdx.x % 5, lane = threadIdx.x / 5;
+    __shared__ double sm[Y3_BNB_SUMS][128][4];
+    const int j = threadIdx.x % Y3_BNB_SUMS, lane = threadIdx.x / Y3_BNB_SUMS;
     const int c0 = blockIdx.x * 4;
     const double* src = reinterpret_cast<const double*>(partials);
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (int t = lane; t < nparts; t += 128) {
-        const double* p = src + ((long long)t * 5 + j) * C + c0;
+        const double* p = src + ((long long)t * Y3_BNB_SUMS + j) * C + c0;
         const double2 lo = *reinterpret_cast<const double2*>(p), hi = *reinterpret_cast<const double2*>(p + 2);
         acc[0] += lo.x;
         acc[1] += lo.y;
@@ -299,8 +316,13 @@ __global__ __launch_bounds__(640) void bn_bwd_finalize_kernel(const float* __res
     }
     if (threadIdx.x < 4) {
         const int e = threadIdx.x, c = c0 + e;
-        const double db = sm[0][0][e], dg = sm[1][0][e], sdys = sm[2][0][e], ss = sm[3][0][e], sxs = sm[4][0][e];
-        const double ga = gamma[c], r = rstd[c], mu = mean[c];
+        const double s0 = sm[0][0][e], s1 = sm[1][0][e], s2 = sm[2][0][e], s3 = sm[3][0][e], s4 = sm[4][0][e], s5 = sm[5][0][e];
+        const double ga = gamma[c], r = rstd[c], mu = mean[c], al = (double)alpha, inv_count = 1.0 / count;
+        const double db = s0;                                                    // sum dy
+        const double dg = r * (s1 - mu * s0);                                    // sum dy * xhat
+        const double sdys = al * s0 + (1.0 - al) * s2;                           // sum dy * slope
+        const double ss = al * count + (1.0 - al) * s4;                          // sum slope
+        const double sxs = r * ((1.0 - al) * (s3 - mu * s4) + al * (s5 - mu * count));   // sum xhat * slope
         // da = ga*r*(dy - db/M - xhat*dg/M);  dz = da*slope;  dbias = sum dz
         dgamma[c] = (float)dg;
         dbeta[c] = (float)db;
@@ -316,12 +338,11 @@ __global__ __launch_bounds__(640) void bn_bwd_finalize_kernel(const float* __res
 extern "C" int y3_bn_bwd_finalize(const float* partials, int nparts, int c, int count, const float* gamma, const float* save_mean,
                                   const float* save_rstd, float alpha, float* dgamma, float* dbeta, float* dbias, float* coef,
                                   y3_stream_t stream) {
-    (void)alpha;
     Y3_CHECK_ARG(partials && gamma && save_mean && save_rstd && dgamma && dbeta && dbias && coef, "bn_bwd_finalize: null pointer");
     Y3_CHECK_ARG(nparts > 0 && c > 0 && count > 0, "bn_bwd_finalize: bad sizes");
     Y3_CHECK_ARG((c & 3) == 0 && ((uintptr_t)partials & 15) == 0, "bn_bwd_finalize: channels must be a multiple of 4, partials 16-byte aligned");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c / 4), dim3(640), 0, (hipStream_t)stream, partials, nparts, c,
-                       1.0 / (double)count, gamma, save_mean, save_rstd, dgamma, dbeta, dbias, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c / 4), dim3(768), 0, (hipStream_t)stream, partials, nparts, c, (double)count, alpha, gamma,
+                       save_mean, save_rstd, dgamma, dbeta, dbias, coef);
     Y3_CHECK_LAUNCH("bn_bwd_finalize");
     return Y3_OK;
 }

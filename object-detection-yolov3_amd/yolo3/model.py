@@ -203,7 +203,8 @@ class _Plan:
         lst.append(entry)
 
     def _bind_conv_workspace(self):
-        self.conv_ws = torch.empty(max(self.conv_ws_bytes // 4, 4), dtype=torch.float32, device=self.model.device)
+        # zeroed once: the head of a conv workspace holds per-tile tickets that every launch leaves at zero (yolo3hip.h)
+        self.conv_ws = torch.zeros(max(self.conv_ws_bytes // 4, 4), dtype=torch.float32, device=self.model.device)
         for lst in (self.fwd, self.bwd):
             for i, e in enumerate(lst):
                 if isinstance(e, list):
@@ -247,7 +248,7 @@ class _Plan:
                        mdl.fold_table().data_ptr(), mdl.fold_layers, BN_EPS)
         if tr:
             self.dz = torch.empty(max_mc, dtype=torch.float32, device=dev)
-            self.bnb_ws = torch.empty(512 * 5 * 1024, dtype=torch.float64, device=dev)      # y3_bn_bwd_partials() <= 512 rows of 5 x C doubles
+            self.bnb_ws = torch.empty(512 * 6 * 1024, dtype=torch.float64, device=dev)      # y3_bn_bwd_partials() <= 512 rows of 6 x C doubles, C <= 1024
             self.wg_ws_bytes = 0
 
         def ptr(off):
@@ -411,7 +412,7 @@ class _Plan:
                 dd = op[3]
                 need = lib.y3_conv2d_wgrad_workspace(src.v, view(self.dz, dd.n, dd.h, dd.w, sp.cout), sp.k, sp.s)
                 wg_need = max(wg_need, int(need))
-        self.wg_ws = torch.empty(max(wg_need // 4, 4), dtype=torch.float32, device=mdl.device)
+        self.wg_ws = torch.zeros(max(wg_need // 4, 4), dtype=torch.float32, device=mdl.device)      # tickets + slabs, zeroed once
         self.wg_ws_bytes = wg_need
 
         first_src = self.x0

@@ -51,7 +51,7 @@ def test_two_rank_step_sums_gradients_and_matches_oracle(tmp_path):
     from dp_worker import make_case
     from oracle import model as om
     from yolo3.model import YoloV3
-    img, n, seed = 96, 2, 11
+    img, n, seed = 96, 4, 11
     anchors, K, params, images, gts = make_case(img, 2 * n, seed)
     # single-process references on each half, global batch = 2n
     singles = []

@@ -48,10 +48,11 @@ def matched_fraction(a_boxes, a_cls, b_boxes, b_cls, iou=0.8):
     return float((m.max(1) >= iou).mean())
 
 
-def sparse_detector(yolo, images, frac=0.003, obj_target=0.3):
+def sparse_detector(yolo, images, frac=0.003, obj_target=0.04):
     """Random-init weights score ~0.5 everywhere (every box a candidate, the NMS order pure rounding noise).  Shift the
     objectness bias of the three heads so that only the top `frac` of the boxes of `images` reach objectness
-    `obj_target`: a detector with sparse, graded detections whose weights are still random.  Returns the weight list."""
+    `obj_target` -- with class probabilities around 0.5 that is where sqrt(obj * cls) crosses the 0.1 score threshold --
+    i.e. a detector with sparse, graded detections whose weights are still random.  Returns the weight list."""
     from oracle import model as om
     params = om.init_params(yolo.img_size[2], len(ANCHORS), K, seed=17, randomize_bn=True)
     for p in params:
@@ -157,10 +158,18 @@ def test_tiled_4k_bf16_against_fp32():
         assert (p[:, 0] >= 0).all() and (p[:, 1] >= 0).all() and (p[:, 2] < 4096).all() and (p[:, 3] < 4096).all()
         assert (p[:, 2] >= p[:, 0]).all() and (p[:, 3] >= p[:, 1]).all()
         assert (p[:, 4] >= 0.1 - 1e-6).all() and (p[:, 4] <= 1.0).all() and np.isin(p[:, 5], [0, 1]).all()
-    f_ab = matched_fraction(p32[:, :4], p32[:, 5], p16[:, :4], p16[:, 5])
-    f_ba = matched_fraction(p16[:, :4], p16[:, 5], p32[:, :4], p32[:, 5])
-    print('matched at IoU >= 0.8: fp32->bf16 %.3f, bf16->fp32 %.3f' % (f_ab, f_ba))
+    # stated agreement: a detection that clears the score threshold by a margin (>= 0.13 against the 0.1 cut) in one
+    # precision must be found in the other at IoU >= 0.8 with the same class in >= 90 % of the cases; boxes AT the
+    # threshold may legitimately flip (bf16 moves a score by up to ~2e-2, see (1)), so all boxes are held to 75 %
+    sure32, sure16 = p32[:, 4] >= 0.13, p16[:, 4] >= 0.13
+    f_ab = matched_fraction(p32[sure32, :4], p32[sure32, 5], p16[:, :4], p16[:, 5])
+    f_ba = matched_fraction(p16[sure16, :4], p16[sure16, 5], p32[:, :4], p32[:, 5])
+    g_ab = matched_fraction(p32[:, :4], p32[:, 5], p16[:, :4], p16[:, 5])
+    g_ba = matched_fraction(p16[:, :4], p16[:, 5], p32[:, :4], p32[:, 5])
+    print('matched at IoU >= 0.8: confident fp32->bf16 %.3f (%d), bf16->fp32 %.3f (%d); all %.3f / %.3f' % (
+        f_ab, int(sure32.sum()), f_ba, int(sure16.sum()), g_ab, g_ba))
     assert f_ab >= 0.9 and f_ba >= 0.9
+    assert g_ab >= 0.75 and g_ba >= 0.75
     assert abs(len(p16) - len(p32)) <= 0.1 * len(p32)
 
 

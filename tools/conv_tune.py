@@ -28,7 +28,7 @@ for (n, h, w, cin, cout, k, s) in SHAPES:
     wt = torch.randn(k * k * cin * cout, device='cuda') * 0.05
     b = torch.zeros(cout, device='cuda')
     stats = torch.empty(n * oh * ow // 16 * cout + 8192, device='cuda')
-    ws = torch.empty(64 << 20, device='cuda')
+    ws = torch.zeros(64 << 20, device='cuda')
     X = _hip.Tensor(x.data_ptr(), n, h, w, cin, cin)
     Y = _hip.Tensor(y.data_ptr(), n, oh, ow, cout, cout)
     res = []

@@ -14,7 +14,7 @@ for mode, (k, cins) in itertools.product(('fwd+stats', 'plain'), ((1, (16, 64, 2
         wt = torch.randn(k * k * cin * cout, device='cuda') * 0.05
         b = torch.zeros(cout, device='cuda')
         stats = torch.empty(n * h * w // 16 * cout + 8192, device='cuda')
-        ws = torch.empty(64 << 20, device='cuda')
+        ws = torch.zeros(64 << 20, device='cuda')
         X = _hip.Tensor(x.data_ptr(), n, h, w, cin, cin)
         Y = _hip.Tensor(y.data_ptr(), n, h, w, cout, cout)
         if mode == 'plain':

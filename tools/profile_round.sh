@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv
 echo "write done"
 python tools/traffic_summary.py $(find $OUT/fetch -name "*counter_collection.csv") $(find $OUT/write -name "*counter_collection.csv") 6 > $OUT/traffic.json
 python tools/layer_times.py > $OUT/layer_times.txt 2>&1
-python tools/trace_union.py $(find $OUT/stats -name "*kernel_trace.csv") 28 > $OUT/trace_union.json
+python tools/trace_union.py $(find $OUT/stats -name "*kernel_trace.csv") > $OUT/trace_union.json
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -size +20M -delete
 ls -la $OUT $OUT/stats
