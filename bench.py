@@ -307,13 +307,17 @@ def main():
     conv_s = min(conv_s, conv_s2)
     achieved = train_fl * BATCH / conv_s / 1e12
     # HBM-side traffic of the same kernel family comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950,
-    # WRITE_SIZE; see profiles/README.md): bench.py cannot run the profiler on itself, so it reports the committed figure
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as fh:
-            traffic = json.load(fh).get('conv_family_hbm_bytes_per_step')
-    except (OSError, ValueError):
-        pass
+    # WRITE_SIZE; see profiles/README.md): bench.py cannot run the profiler on itself, so it reports the figure committed in
+    # the SAME round as the kernels it times (profiles/rNN_traffic.json, newest first) and says which file it was
+    traffic, traffic_src = None, None
+    for tag in ('r02', 'r01'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', '%s_traffic.json' % tag)) as fh:
+                traffic = json.load(fh).get('conv_family_hbm_bytes_per_step')
+                traffic_src = 'profiles/%s_traffic.json' % tag
+                break
+        except (OSError, ValueError):
+            pass
 
     # secondary (BASELINE.json configs[1]): inference bs=8 416x416 fp32 -- z-scored batch -> conv stacks with folded BN ->
     # decode -> clip + small-box filter + class-wise NMS, all on the GPU; reported beside the headline metric
@@ -371,8 +375,9 @@ def main():
                        'global_batch': global_batch, 'per_gpu_batch': BATCH, 'image': [IMG, IMG, 3],
                        'launch': 'hip-graph' if use_graph else 'host launches, kernel gradients on a second stream', 'parallelism': 'dp%d' % world},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
-                         'kernel': 'conv_igemm_kernel + conv_wgrad_kernel (MFMA implicit-GEMM conv fwd/dgrad/wgrad), %d launches/step; achieved = flops / union of their busy intervals' % sum(v[1] for v in per.values()),
+                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'kernel': 'conv_igemm_fast_kernel + conv_wgrad_kernel (MFMA implicit-GEMM conv fwd/dgrad/wgrad, split-K reduced in-kernel), %d launches/step; achieved = flops / union of their busy intervals' % sum(v[1] for v in per.values()),
+                         'peak_note': 'peak = 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz; under this load the chip holds 2.0-2.2 GHz (tools/probe/conv_timing), i.e. 131-144 TFLOP/s',
                          'flops_per_step': train_fl * BATCH, 'kernel_ms_per_step': conv_s * 1e3,
                          'by_entry_ms': {k: round(v[0] * 1e3, 3) for k, v in per.items()}},
             'step_flop_rate_tflops': train_fl * BATCH / (dt / args.steps) / 1e12,

@@ -51,6 +51,14 @@ __device__ __forceinline__ int y3_xcd_remap(int orig, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
+// Workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it (a plain
+// __syncthreads() also waits for vmcnt(0)).
+__device__ __forceinline__ void y3_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ float y3_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

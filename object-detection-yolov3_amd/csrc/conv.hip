@@ -327,13 +327,6 @@ template <int... I, class F>
 __device__ __forceinline__ void y3_for_each_ic(std::integer_sequence<int, I...>, F&& f) {
     (f(std::integral_constant<int, I>{}), ...);
 }
-// Workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it (a plain
-// __syncthreads() also waits for vmcnt(0)).
-__device__ __forceinline__ void y3_lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
 // Instruction-mix directives for the machine scheduler (masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write)
 template <int MASK, int N>
 __device__ __forceinline__ void y3_sgb() {

@@ -26,6 +26,8 @@ struct Bf16Args {
     int tap_off[9];  // bytes
     int tap_wt[9];   // element offset of tap t in wt (t * Cout * Cin)
     int tap_dh[9], tap_dw[9];
+    int tap_off0, tap_wt1;         // tap_off[0], tap_wt[1] (= Cout * Cin)
+    int tg_nx, tg_offy, tg_offx;   // tap_off as an affine map of the tap grid (tap = ty * tg_nx + tx): no table lookup in the K loop
     unsigned src_bytes, wt_bytes, dst_bytes, resid_bytes;
     int ntaps;
     int H, W, C, logC, cmask, src_ld;
@@ -38,6 +40,14 @@ struct Bf16Args {
 };
 
 #define Y3_OOB 0x80000000u
+// buffer_load_dwordx4 ... lds.  The builtin needs a gfx950 target feature; in the HOST pass of the same compilation the
+// template body would be invalid and clang then silently drops the kernel's launch stub (undefined __device_stub__ at load
+// time), so the host pass sees an empty statement.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define Y3_GLDS16(rsrc, lds_dst, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds_dst, 16, voff, soff, 0, 0)
+#else
+#define Y3_GLDS16(rsrc, lds_dst, voff, soff) ((void)(rsrc), (void)(lds_dst), (void)(voff), (void)(soff))
+#endif
 
 // Development instrumentation (tools/probe/bf16_timing.hip builds this file with -DY3_TIMING): per-workgroup timestamps
 // of the kernel phases.  Compiled out of the product library.
@@ -64,7 +74,7 @@ constexpr int stage_rows(int bm, int tm, int cap) {
     return best;
 }
 
-template <int BM, int BN, int WM, int WN, bool STAGED, int BK = 32>
+template <int BM, int BN, int WM, int WN, bool STAGED, int BK = 32, int NBUF = 3>
 __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args p) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int Q = BK / 8;             // 16-byte quads per row and K step (BK = 32: 64-byte rows, 64: 128-byte rows)
@@ -77,12 +87,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
     constexpr int A_LOADS = BM * Q / THREADS, B_LOADS = (BN * Q + THREADS - 1) / THREADS;
     static_assert(BM * Q % THREADS == 0 && TM % 32 == 0 && TN % 32 == 0 && (BK == 32 || BK == 64), "tile shape");
 
-    // one LDS block: [2][BM] + [2][BN] operand rows in the main loop, re-used as the fp32 staging tile of the epilogue
+    // ONE LDS block (a second __shared__ object beside an LDS-DMA staging array makes hipcc drain vmcnt before every
+    // ds_read, cdna_hip_programming.md 5): a ring of NBUF operand stages {A rows | B rows} in the main loop, re-used as the
+    // fp32 staging tile of the epilogue.  B holds at least one full wave-load of rows so that every wave issues the same
+    // number of LDS-DMA loads per K step (the counted vmcnt below relies on it); surplus rows receive zeros.
+    constexpr int BROWS = B_LOADS * THREADS / Q;          // >= BN
+    constexpr int STG_U16 = (BM + BROWS) * LDR;            // one ring stage
     constexpr int STAGE_U16 = (BM / WM) * (BN + 4) * 2;    // one wave-row band of the fp32 staging tile of the epilogue
-    constexpr int OPER_U16 = 2 * (BM + BN) * LDR;
+    constexpr int OPER_U16 = NBUF * STG_U16;
     __shared__ __attribute__((aligned(16))) u16 smem[OPER_U16 > STAGE_U16 ? OPER_U16 : STAGE_U16];
-    u16(*As)[BM * LDR] = reinterpret_cast<u16(*)[BM * LDR]>(smem);
-    u16(*Bs)[BN * LDR] = reinterpret_cast<u16(*)[BN * LDR]>(smem + 2 * BM * LDR);
 
     Y3_TSTAMP(0);
 #ifdef Y3_TIMING
@@ -115,7 +128,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
         const int oh = r / p.OW;
         const int ow = r - oh * p.OW;
         const int ih0 = oh * p.sh, iw0 = ow * p.sw;
-        a_voff[i] = (unsigned)(((n * p.H + ih0) * p.W + iw0) * p.src_ld + quad * 8) * 2u;
+        // LDS-DMA writes lane l of a wave to (wave-uniform base) + 16 * l: the LDS image is lane-linear, so the XOR swizzle of
+        // the 16-byte quads is applied to the SOURCE address: the lane that fills slot `quad` of row `row` fetches quad
+        // quad ^ f(row)
+        const int qsrc = quad ^ ((row >> SWZ_SHIFT) & SWZ_MASK);
+        a_voff[i] = (unsigned)(((n * p.H + ih0) * p.W + iw0) * p.src_ld + qsrc * 8) * 2u;
         unsigned msk = 0;
         for (int t = 0; t < p.ntaps; ++t) {
             const int ih = ih0 + p.tap_dh[t], iw = iw0 + p.tap_dw[t];
@@ -127,43 +144,38 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
         const int idx = tid + i * THREADS;
-        const int n = n0 + idx / Q;
-        b_voff[i] = (idx < BN * Q && n < p.Nout) ? (unsigned)(n * p.C + quad * 8) * 2u : Y3_OOB;
+        const int row = idx / Q, n = n0 + row;
+        const int qsrc = quad ^ ((row >> SWZ_SHIFT) & SWZ_MASK);
+        b_voff[i] = (idx < BN * Q && n < p.Nout) ? (unsigned)(n * p.C + qsrc * 8) * 2u : Y3_OOB;
     }
 
-    // two register stages: the loads of K step s go to stage s & 1 and are written to LDS one iteration later, so a load
-    // has a full iteration (all resident waves' MFMAs) plus its own step to land -- with 16x the fp32 MFMA rate a single
-    // step of compute (8 MFMAs per wave) is far shorter than an L2 round trip
-    f32x4 ra[2][A_LOADS], rb[2][B_LOADS];
-    auto gload = [&](int k0, auto stage) {
-        constexpr int S = decltype(stage)::value;
+    // Operand staging by LDS-DMA (buffer_load_dwordx4 ... lds): global -> LDS with no VGPR hop and no ds_write.  With 16x
+    // the fp32 MFMA rate the register-staged version of this loop was bound by the LDS STORE path (4 ds_write_b128 per wave
+    // and K step at ~13 cycles each against 256 cycles of MFMA, 3 workgroups per CU) and by the two register stages it needed
+    // to cover an L2 round trip.  Here a K step is 2 + 2 DMA instructions per wave (1 KiB each: 16 consecutive tile rows,
+    // lane l -> slot l), a ring of NBUF = 3 stages keeps two steps in flight, and out-of-range lanes (zero padding, tile
+    // edges) point past the descriptor and deposit zeros (probed: tools/probe/lds_dma_probe.hip).
+    auto glds = [&](int k0, int buf) {
+        // tap -> offsets by arithmetic: indexing the argument-segment tables is a scalar MEMORY load in the loop, which forces
+        // every later LDS wait to lgkmcnt(0) (see conv.hip)
         const int tap = k0 >> p.logC;
         const int cb = k0 & p.cmask;
-        const unsigned a_soff = (unsigned)(p.tap_off[tap] + cb * 2);
-        const unsigned b_soff = (unsigned)(p.tap_wt[tap] + cb) * 2u;
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i)
-            ra[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, ((a_mask[i] >> tap) & 1u) ? a_voff[i] : Y3_OOB, a_soff, 0);
-#pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[i], b_soff, 0);
-    };
-    auto lstore = [&](int buf, auto stage) {
-        constexpr int S = decltype(stage)::value;
+        const int ty = p.tg_nx == 1 ? tap : (tap * 11) >> 5;      // tap / 3 for tap < 9
+        const int tx = tap - ty * p.tg_nx;
+        const unsigned a_soff = (unsigned)(p.tap_off0 + ty * p.tg_offy + tx * p.tg_offx + cb * 2);
+        const unsigned b_soff = (unsigned)(tap * p.tap_wt1 + cb) * 2u;
+        u16* stage = smem + buf * STG_U16;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const int row = (tid + i * THREADS) / Q;
-            *reinterpret_cast<f32x4*>(&As[buf][row * LDR + ((quad ^ ((row >> SWZ_SHIFT) & SWZ_MASK)) * 8)]) = ra[S][i];
+            u16* dst = stage + (wave * (64 / Q) + i * (THREADS / Q)) * LDR;     // wave-uniform: becomes M0
+            Y3_GLDS16(rs_src, dst, ((a_mask[i] >> tap) & 1u) ? a_voff[i] : Y3_OOB, a_soff);
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
-            const int idx = tid + i * THREADS;
-            const int row = idx / Q;
-            if (BN * Q % THREADS == 0 || idx < BN * Q)
-                *reinterpret_cast<f32x4*>(&Bs[buf][row * LDR + ((quad ^ ((row >> SWZ_SHIFT) & SWZ_MASK)) * 8)]) = rb[S][i];
+            u16* dst = stage + (BM + wave * (64 / Q) + i * (THREADS / Q)) * LDR;
+            Y3_GLDS16(rs_wt, dst, b_voff[i], b_soff);
         }
     };
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
 
     f32x16 acc[MB][NB];
 #pragma unroll
@@ -174,9 +186,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = p.K / BK;
-    auto compute = [&](int cur) {
-        const u16* as = &As[cur][(wm * TM + l31) * LDR];
-        const u16* bs = &Bs[cur][(wn * TN + l31) * LDR];
+    auto compute = [&](int buf) {
+        const u16* as = smem + buf * STG_U16 + (wm * TM + l31) * LDR;
+        const u16* bs = smem + buf * STG_U16 + (BM + wn * TN + l31) * LDR;
         const int swz = (l31 >> SWZ_SHIFT) & SWZ_MASK;      // rows advance in multiples of 32 per fragment: f(row) = f(l31)
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
@@ -192,27 +204,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
                 for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
     };
-    // every load / LDS store below is unconditional (steps past the end re-load the last step and are never read), so
-    // the compiler's vmcnt bookkeeping stays exact: the store of stage s waits for its 4 loads only, not the 4 newer ones
+    // Every wave issues exactly L = A_LOADS + B_LOADS DMA instructions per step, steps past the end re-load the last step
+    // into a stage nobody reads, so "all but the newest L are done" (s_waitcnt vmcnt(L)) always means "step ks has landed".
+    // The barrier is a raw s_barrier + lgkmcnt(0): __syncthreads() would also drain vmcnt and with it the step in flight.
+    constexpr int L = A_LOADS + B_LOADS, AHEAD = NBUF - 1;     // steps in flight
+    static_assert(L * (AHEAD - 1) < 16, "vmcnt immediate");
     const int klast = p.K - BK;
-    gload(0, S0{});
-    gload(min(BK, klast), S1{});
-    lstore(0, S0{});
-    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) glds(min(a * BK, klast), a);
     Y3_TSTAMP(1);
-    for (int ks = 0; ks < nk; ks += 2) {
-        // even step ks: LDS buffer 0; stage 0 is free (stored last iteration), stage 1 holds step ks + 1
-        gload(min((ks + 2) * BK, klast), S0{});
-        compute(0);
-        lstore(1, S1{});
-        __syncthreads();
-        if (ks + 1 >= nk) break;
-        // odd step ks + 1: LDS buffer 1; stage 1 free, stage 0 holds step ks + 2
-        gload(min((ks + 3) * BK, klast), S1{});
-        compute(1);
-        lstore(0, S0{});
-        __syncthreads();
+    int buf = 0, nbuf = AHEAD;
+    for (int ks = 0; ks < nk; ++ks) {
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (L * (AHEAD - 1)));   // all but the newest AHEAD - 1 steps: this wave's part of step ks is in LDS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's fragment reads of step ks - 1 have returned
+        __builtin_amdgcn_s_barrier();                       // ... and so have everybody's: stage (ks - 1) % NBUF is free
+        glds(min((ks + AHEAD) * BK, klast), nbuf);
+        compute(buf);
+        buf = buf == NBUF - 1 ? 0 : buf + 1;
+        nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): no DMA may land in the block the epilogue re-uses
+    __syncthreads();
 
     Y3_TSTAMP(2);
     if constexpr (!STAGED) {
@@ -471,7 +483,18 @@ static int check_bf16_tensor(const y3_tensor* t, const char* name) {
 
 template <int BM, int BN, int WM, int WN, bool STAGED = true, int BK = 32>
 static void launch_bf16(const Bf16Args& p, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, WM, WN, STAGED, BK>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
+    static const int nbuf = getenv("Y3_BF16_NBUF") ? atoi(getenv("Y3_BF16_NBUF")) : 3;     // ring depth (experiments): 2, 3 or 4
+    if constexpr (BK == 32 && BM * BN <= 128 * 128) {
+        if (nbuf == 4) {
+            hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, WM, WN, STAGED, BK, 4>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
+            return;
+        }
+        if (nbuf == 2) {
+            hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, WM, WN, STAGED, BK, 2>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, WM, WN, STAGED, BK, 3>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
 }
 
 extern "C" int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, const float* bias, int ksize, int stride, const y3_tensor* dst,
@@ -503,6 +526,12 @@ extern "C" int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, c
         p.tap_off[t] = ((p.tap_dh[t] * src->w + p.tap_dw[t]) * src->ld - min_off) * 2;
         p.tap_wt[t] = t * dst->c * src->c;
     }
+    // the same as affine maps of the (ksize x ksize) tap grid, tap = ty * ksize + tx
+    p.tg_nx = ksize;
+    p.tap_off0 = p.tap_off[0];
+    p.tap_wt1 = dst->c * src->c;
+    p.tg_offx = ksize > 1 ? p.tap_off[1] - p.tap_off[0] : 0;
+    p.tg_offy = ksize > 1 ? p.tap_off[ksize] - p.tap_off[0] : 0;
     const long long sbytes = ((long long)src->n * src->h * src->w * src->ld - min_off) * 2;
     const long long wbytes = (long long)taps * dst->c * src->c * 2;
     const long long M = (long long)src->n * OH * OW;

@@ -1,4 +1,4 @@
-"""Time y3_conv2d_fwd / dgrad on the network's main shapes under the tile forced by Y3_TILE (development tool).
+"""Time y3_conv2d_fwd / dgrad / wgrad on the network's main shapes under the tile forced by Y3_TILE (development tool).
     Y3_TILE=128,128,32 python tools/conv_tune.py"""
 import os
 import sys
@@ -32,10 +32,14 @@ for (n, h, w, cin, cout, k, s) in SHAPES:
     X = _hip.Tensor(x.data_ptr(), n, h, w, cin, cin)
     Y = _hip.Tensor(y.data_ptr(), n, oh, ow, cout, cout)
     res = []
-    for mode in ('fwd', 'dgrad'):
+    dw = torch.empty(k * k * cin * cout, device='cuda')
+    wws = torch.zeros(int(_hip.lib.y3_conv2d_wgrad_workspace(X, Y, k, s)) // 4 + 16, device='cuda')
+    for mode in ('fwd', 'dgrad', 'wgrad'):
         def run():
             if mode == 'fwd':
                 return _hip.lib.y3_conv2d_fwd(X, wt.data_ptr(), b.data_ptr(), k, s, Y, _hip.EPI_LRELU, 0.2, None, None, None, stats.data_ptr(), ws.data_ptr(), ws.numel() * 4, st)
+            if mode == 'wgrad':
+                return _hip.lib.y3_conv2d_wgrad(X, Y, k, s, dw.data_ptr(), wws.data_ptr(), wws.numel() * 4, st)
             return _hip.lib.y3_conv2d_dgrad(Y, wt.data_ptr(), k, s, X, 0, ws.data_ptr(), ws.numel() * 4, st)
         rc = run()
         if rc != 0:

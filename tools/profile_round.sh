@@ -2,7 +2,7 @@
 # Refresh the judged measurements of a round on the GPU box:  bash tools/profile_round.sh r01
 # Writes under gpurun_out/<tag>/ ; copy the summaries into profiles/ afterwards (tools/traffic_summary.py for the PMC passes).
 set -e -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -17,6 +17,11 @@ echo "write done"
 python tools/traffic_summary.py $(find $OUT/fetch -name "*counter_collection.csv") $(find $OUT/write -name "*counter_collection.csv") 6 > $OUT/traffic.json
 python tools/layer_times.py > $OUT/layer_times.txt 2>&1
 python tools/trace_union.py $(find $OUT/stats -name "*kernel_trace.csv") > $OUT/trace_union.json
+# MFMA utilisation of the shipping conv kernels: one counter pass over the per-shape driver (program directly after --)
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc -o p --output-format csv -- python3 tools/conv_tune.py > $OUT/pmc_conv_tune.txt 2> $OUT/rocprof_pmc.err
+python tools/pmc_summary.py $(find $OUT/pmc -name "*counter_collection.csv") conv_ > $OUT/pmc_conv.txt
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmcb -o p --output-format csv -- python3 tools/bf16_probe.py > $OUT/pmc_bf16_probe.txt 2> $OUT/rocprof_pmcb.err
+python tools/pmc_summary.py $(find $OUT/pmcb -name "*counter_collection.csv") conv_bf16 > $OUT/pmc_bf16.txt
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -size +20M -delete
 ls -la $OUT $OUT/stats

@@ -6,7 +6,7 @@ import csv
 import json
 import sys
 
-FAMILY = ('conv_igemm', 'conv_wgrad', 'splitk_epilogue', 'slab_reduce')
+FAMILY = ('conv_igemm', 'conv_wgrad', 'splitk_epilogue', 'slab_reduce')    # splitk_epilogue: round 1 only
 
 
 def total(path, counter):
