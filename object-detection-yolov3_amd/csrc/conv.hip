@@ -291,7 +291,7 @@ struct FastArgs {
     int Nout, K, M;
     unsigned flags;
     float alpha;
-    int nbn;
+    int nbn, nbm, col_major;
     // Split-K with the reduction inside the kernel.  Work items: tiles [0, sk_f) are cut into sk_s0 K slices each, tiles
     // [sk_f, tiles) into sk_s1 (the remainder of a launch whose tile count is not a multiple of the CU count is split
     // finer so that every CU ends up with the same amount of MFMA work).  Item i < sk_n0 = sk_f * sk_s0 is slice
@@ -381,7 +381,13 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int bid0
         nz = p.sk_s1;
         kchunk = p.sk_chunk1;
     }
-    const int bm = bid / p.nbn, bn = bid % p.nbn;
+    // tile id -> (row tile, column tile).  Ids are contiguous per XCD (y3_xcd_remap), so the fastest-varying coordinate decides
+    // which operand an XCD's private 4 MB L2 keeps: row-major ids walk all column tiles of a few row tiles (the activation
+    // rows stay, the whole kernel matrix streams through once per row tile), column-major ids walk all row tiles of a few
+    // column tiles (a slice of the kernel matrix stays, the activations stream).  The host picks column-major when the kernel
+    // matrix is too large to stay resident (> 2 MB): 13x13 512->1024 3x3 fetched its 18.9 MB of weights ~24 times per launch.
+    const int bm = p.col_major ? bid % p.nbm : bid / p.nbn;
+    const int bn = p.col_major ? bid / p.nbm : bid % p.nbn;
     const int m0 = bm * BM, n0 = bn * BN;
     const int ohw = p.OH * p.OW;
     const int kbeg = kz * kchunk * BK;
@@ -875,7 +881,7 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_multi_kernel(
     int c = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i) c += ((int)blockIdx.x >= m.first[i]) ? 1 : 0;
-    conv_fast_body<BM, BN, WM, WN, BK, false>(m.a[c], y3_xcd_remap((int)blockIdx.x - m.first[c], m.first[c + 1] - m.first[c]));
+    conv_fast_body<BM, BN, WM, WN, BK, false, 2>(m.a[c], y3_xcd_remap((int)blockIdx.x - m.first[c], m.first[c + 1] - m.first[c]));
 }
 
 // ---------------------------------------------------------------------------
@@ -1343,7 +1349,7 @@ static ConvPlan plan_conv(int M, int Nout, int K, bool fast_ok) {
     pl.f = tiles;
     pl.s0 = pl.s1 = 1;
     pl.chunk0 = pl.chunk1 = nk > 0 ? nk : 1;
-    static const int want = env_int("Y3_SPLITK_WGS", 1400);   // workgroups to aim for
+    static const int want = env_int("Y3_SPLITK_WGS", 2000);   // workgroups to aim for (swept with tools/fwd_time.py: 1000 / 1400 / 2000 / 2800)
     static const int min_k = env_int("Y3_SPLITK_MINK", 256);  // shortest K slice worth a launch
     static const int cus = env_int("Y3_CUS", 256);
     static const int rsplit_on = env_int("Y3_RSPLIT", 1);
@@ -1538,6 +1544,9 @@ static int launch_igemm(const ConvArgs& a, void* workspace, size_t workspace_byt
     FastArgs f;
     if (fast_ok && make_fast(p, ntaps, t.bk, &f)) {
         f.nbn = p.nbn;
+        f.nbm = y3_cdiv(p.M, t.bm);
+        static const int colmajor_kb = env_int("Y3_COLMAJOR_KB", 2048);     // kernel matrix larger than this: column-major tile ids
+        f.col_major = ((long long)p.K * p.Nout * 4 > (long long)colmajor_kb * 1024) ? 1 : 0;
         f.sk_f = pl.f;
         f.sk_s0 = pl.s0;
         f.sk_s1 = pl.s1;
@@ -1691,6 +1700,8 @@ static bool launch_dgrad_multi(const ConvArgs* cls, int ncls, hipStream_t st) {
         const int ntaps = cls[c].K / cls[c].C;
         if (!fast_shape_ok(cls[c].C, cls[c].Nout, cls[c].K, ntaps) || !make_fast(cls[c], ntaps, t.bk, &m.a[c])) return false;
         m.a[c].nbn = y3_cdiv(cls[c].Nout, t.bn);
+        m.a[c].nbm = y3_cdiv(cls[c].M, t.bm);
+        m.a[c].col_major = 0;
         m.a[c].sk_f = m.a[c].sk_n0 = y3_cdiv(cls[c].M, t.bm) * m.a[c].nbn;   // whole tiles only
         m.a[c].sk_s0 = m.a[c].sk_s1 = 1;
         m.a[c].sk_chunk0 = m.a[c].sk_chunk1 = cls[c].K / t.bk;

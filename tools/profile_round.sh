@@ -20,8 +20,10 @@ python tools/trace_union.py $(find $OUT/stats -name "*kernel_trace.csv") > $OUT/
 # MFMA utilisation of the shipping conv kernels: one counter pass over the per-shape driver (program directly after --)
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc -o p --output-format csv -- python3 tools/conv_tune.py > $OUT/pmc_conv_tune.txt 2> $OUT/rocprof_pmc.err
 python tools/pmc_summary.py $(find $OUT/pmc -name "*counter_collection.csv") conv_ > $OUT/pmc_conv.txt
+python tools/mfma_util.py $(find $OUT/pmc -name "*counter_collection.csv") conv_ > $OUT/mfma_util_conv.md
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmcb -o p --output-format csv -- python3 tools/bf16_probe.py > $OUT/pmc_bf16_probe.txt 2> $OUT/rocprof_pmcb.err
 python tools/pmc_summary.py $(find $OUT/pmcb -name "*counter_collection.csv") conv_bf16 > $OUT/pmc_bf16.txt
+python tools/mfma_util.py $(find $OUT/pmcb -name "*counter_collection.csv") conv_bf16 > $OUT/mfma_util_bf16.md
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -size +20M -delete
 ls -la $OUT $OUT/stats
