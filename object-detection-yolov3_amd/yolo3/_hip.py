@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, '_lib', 'libyolo3hip.so')
+LIB_PATH = os.environ.get('Y3_LIB') or os.path.join(_HERE, '_lib', 'libyolo3hip.so')     # Y3_LIB: A/B two builds (tools/)
 
 
 class HipLibraryMissing(ImportError):
