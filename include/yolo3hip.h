@@ -128,21 +128,20 @@ int y3_bn_apply(const y3_tensor* a, const float* scale, const float* shift, cons
                 const y3_tensor* y, y3_stream_t stream);
 /*
  * Backward of conv_layer's tail  y = BN(lrelu(z)):  given dy and a = lrelu(z)
- *   step 1 (reduce):   per-channel partial sums (raw moments of (dy, a), fp64) -> workspace.
- *                      Channels: c % 4 == 0, c <= 1024 and (c / 4) must divide 256 (true for every layer of
- *                      this network: 32 ... 1024); save_mean / save_rstd / alpha are accepted for symmetry
- *                      and used by step 2 only.
- *   step 2 (finalize): dgamma, dbeta, dbias (bias gradient of the conv) and
- *                      the per-channel coefficients k1,k2,k3 (coef[3][c])
- *   step 3 (apply):    dz = (k1*dy + k2*a + k3) * (a > 0 ? 1 : alpha)
+ *   step 1 (stats):  per-channel raw moments of (dy, a) in fp64 (workspace), then -- by the workgroup whose partial
+ *                    arrives last, inside the same launch -- dgamma, dbeta, dbias (bias gradient of the conv) and the
+ *                    per-channel coefficients k1,k2,k3 (coef[3][c]).  Optionally the residual fan-in of model.py:47
+ *                    rides along while dy streams through: dres = dy (dres_accumulate == 0) or dres += dy.
+ *                    Channels: a multiple of 64 up to 1024, or 4 / 8 / 16 / 32 (every layer of this network).
+ *                    `workspace`: y3_bn_bwd_workspace(m, c) bytes, 16-byte aligned; its first 1 KiB (tickets) must be
+ *                    zero before the FIRST call -- every call leaves it zero again.
+ *   step 2 (apply):  dz = (k1*dy + k2*a + k3) * (a > 0 ? 1 : alpha)
  */
-int y3_bn_bwd_reduce(const y3_tensor* dy, const y3_tensor* a, const float* save_mean,
-                     const float* save_rstd, float alpha, float* partials, int* nparts,
-                     y3_stream_t stream);
-int y3_bn_bwd_partials(int m, int c); /* number of partial rows; `partials` holds rows*6*c DOUBLES (16-byte aligned) */
-int y3_bn_bwd_finalize(const float* partials, int nparts, int c, int count, const float* gamma,
-                       const float* save_mean, const float* save_rstd, float alpha,
-                       float* dgamma, float* dbeta, float* dbias, float* coef, y3_stream_t stream);
+int y3_bn_bwd_stats(const y3_tensor* dy, const y3_tensor* a, const y3_tensor* dres, int dres_accumulate,
+                    const float* gamma, const float* save_mean, const float* save_rstd, float alpha,
+                    float* dgamma, float* dbeta, float* dbias, float* coef,
+                    void* workspace, size_t workspace_bytes, y3_stream_t stream);
+size_t y3_bn_bwd_workspace(int m, int c); /* 0 if the channel count is unsupported */
 int y3_bn_bwd_apply(const y3_tensor* dy, const y3_tensor* a, const float* coef, float alpha,
                     const y3_tensor* dz, y3_stream_t stream);
 

@@ -1400,7 +1400,7 @@ static ConvPlan plan_conv(int M, int Nout, int K, bool fast_ok) {
     return pl;
 }
 static bool fast_shape_ok(int C, int Nout, int K, int ntaps) {
-    return !getenv("Y3_NO_FAST") && C % 16 == 0 && (Nout & 3) == 0 && K % 16 == 0 && (ntaps == 1 || y3_is_pow2(C));
+    return !getenv("Y3_NO_FAST") && C % 16 == 0 && K % 16 == 0 && (ntaps == 1 || y3_is_pow2(C));
 }
 
 extern "C" int y3_conv2d_stats_tiles(int m, int cin, int ksize, int cout) {
@@ -1440,7 +1440,9 @@ static void launch_fast(const FastArgs& p, bool dense, int grid, hipStream_t st)
 
 // Build the fast kernel's arguments; false if the launch does not qualify.
 static bool make_fast(const ConvArgs& a, int ntaps, int bk, FastArgs* f) {
-    if (a.C % bk != 0 || (a.Nout & 3) != 0 || a.K % bk != 0) return false;
+    // Nout need not be a multiple of 4 (the detection heads): a weight-row load that runs past column Nout - 1 picks up the
+    // head of the next row (zeros past the end of the buffer) into accumulator columns >= Nout, which the epilogue never stores
+    if (a.C % bk != 0 || a.K % bk != 0) return false;
     if (ntaps > 1 && !y3_is_pow2(a.C)) return false;
     const long long src_elems = (long long)(a.M > 0 ? 1 : 0) * 0;  // (unused)
     (void)src_elems;

@@ -172,43 +172,89 @@ extern "C" int y3_bn_apply(const y3_tensor* a, const float* scale, const float* 
 // ---------------------------------------------------------------------------
 // BatchNorm + leaky-relu backward
 // ---------------------------------------------------------------------------
-#define Y3_BNB_MAXPARTS 512           // 2 blocks per CU; more parts did not speed the reduce up and slow the finalize down (measured)
 #define Y3_BNB_SUMS 6
-extern "C" int y3_bn_bwd_partials(int m, int c) {
-    if (c < 4 || c > 1024) return 1;
-    const int rows_per_pass = 256 / (c / 4);
-    int parts = y3_cdiv(m, (long long)rows_per_pass * 4);
-    if (parts > Y3_BNB_MAXPARTS) parts = Y3_BNB_MAXPARTS;
+#define Y3_BNB_BLOCKS 256             // workgroups per launch (one per CU): 512 stream no faster and double the last arrival's work (measured)
+#define Y3_BNB_TICKETS 1024           // bytes of tickets (one int per channel slice, <= 16 slices) at the head of the workspace
+
+// A workgroup streams a band of rows of ONE channel slice: lc float4 lanes (<= 8: 32 channels) x 256/lc row groups.  Slicing
+// the channels keeps the fp64 partials at parts * slices * 6 * 32 doubles <= 384 KiB whatever C is (whole-row workgroups
+// wrote up to 25 MiB of partials for the 1024-channel layers, more than the tensors they reduce).
+struct BnbPlan {
+    int lc, sw, slices, parts;
+};
+static bool plan_bnb(long long m, int c, BnbPlan* p) {
+    if (c < 4 || c > 1024 || (c & 3)) return false;
+    static const int lcap = getenv("Y3_BNB_LC") ? atoi(getenv("Y3_BNB_LC")) : 8;      // 8 float4 lanes = one 128-byte line per row
+    p->lc = c / 4 < lcap ? c / 4 : lcap;
+    if (p->lc & (p->lc - 1)) return false;
+    p->sw = 4 * p->lc;
+    if (c % p->sw) return false;
+    p->slices = c / p->sw;
+    long long parts = y3_cdiv(m, (long long)(256 / p->lc) * 4);
+    static const int blocks = getenv("Y3_BNB_BLOCKS") ? atoi(getenv("Y3_BNB_BLOCKS")) : Y3_BNB_BLOCKS;
+    int cap = (blocks < Y3_BNB_BLOCKS ? blocks : Y3_BNB_BLOCKS) / p->slices;
+    if (cap < 1) cap = 1;
+    if (parts > cap) parts = cap;
     if (parts < 1) parts = 1;
-    return parts;
+    p->parts = (int)parts;
+    return true;
+}
+extern "C" size_t y3_bn_bwd_workspace(int m, int c) {
+    BnbPlan p;
+    if (!plan_bnb(m, c, &p)) return 0;
+    return (size_t)Y3_BNB_TICKETS + (size_t)p.parts * p.slices * Y3_BNB_SUMS * p.sw * sizeof(double);
 }
 
-// partials[part][6][C] (fp64), raw moments of (dy, a):
+struct BnbArgs {
+    const float* dy;
+    const float* a;
+    float* dres;          // optional: gradient of the residual input, dres (+)= dy while dy streams through
+    double* partials;     // [slice][part][6][sw]
+    int* tickets;
+    const float* gamma;
+    const float* mean;
+    const float* rstd;
+    float* dgamma;
+    float* dbeta;
+    float* dbias;
+    float* coef;
+    long long npix;
+    double count;
+    int dy_ld, a_ld, dres_ld, dres_acc;
+    int C, lc, slices, parts;
+    float alpha;
+};
+
+// Raw moments of (dy, a), fp64:
 //   S0 = sum dy, S1 = sum dy*a, S2 = sum_{a>0} dy, S3 = sum_{a>0} a, S4 = #{a>0}, S5 = sum a
 // The leaky-relu slope s is 1 for a > 0 and alpha otherwise, so with xhat = (a - mu) * r
 //   sum dy*xhat = r*(S1 - mu*S0),  sum dy*s = alpha*S0 + (1-alpha)*S2,  sum s = alpha*M + (1-alpha)*S4,
 //   sum xhat*s  = r*((1-alpha)*(S3 - mu*S4) + alpha*(S5 - mu*M))
-// (bn_bwd_finalize does that algebra in fp64).  Raw moments keep the per-element work at two conversions, one fma and a
-// few (masked) adds, and the kernel no longer needs the saved mean / rstd.
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int dy_ld, const float* __restrict__ a, int a_ld,
-                                                            float* __restrict__ partials, long long npix, int C) {
-    // fp64 accumulation: dbias is a small difference of these sums (BatchNorm removes the mean shift a
-    // bias introduces), so fp32 running sums would lose it to cancellation
+// Raw moments keep the per-element work at two conversions, one fma and a few (masked) adds.  fp64 accumulation: dbias is a
+// small difference of these sums (BatchNorm removes the mean shift a bias introduces), fp32 running sums lose it to
+// cancellation.
+// The workgroup whose partial arrives LAST for a channel slice (ticket, as in the split-K convolutions: sc1 stores, vmcnt
+// drained, one agent-scope atomic add) sums the slice's partials in part order -- the result does not depend on which
+// workgroup that was -- and writes dgamma / dbeta / dbias and the coefficients of bn_bwd_apply.  No second launch.
+template <bool RES>
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const BnbArgs p) {
     __shared__ double sm[256 * 4 * Y3_BNB_SUMS];
-    const int c4n = C >> 2;
-    const int rpp = 256 / c4n;
-    const int cq = threadIdx.x % c4n, rg = threadIdx.x / c4n;
-    const int c = cq * 4;
+    __shared__ int last_flag;
+    const int tid = threadIdx.x;
+    const int lc = p.lc, rgn = 256 / lc, sw = 4 * lc;
+    const int slice = blockIdx.x % p.slices, part = blockIdx.x / p.slices;
+    const int cq = tid % lc, rg = tid / lc;
+    const int c = slice * sw + cq * 4;
     double acc[5][4];
     int cnt[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 5; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[j][e] = 0.0;
-    const long long rows_per_block = (npix + gridDim.x - 1) / gridDim.x;
-    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long rows_per_block = (p.npix + p.parts - 1) / p.parts;
+    const long long r0 = (long long)part * rows_per_block;
     long long r1 = r0 + rows_per_block;
-    if (r1 > npix) r1 = npix;
+    if (r1 > p.npix) r1 = p.npix;
     auto accumulate = [&](const float4 d4, const float4 a4) {
         const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
@@ -223,127 +269,192 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             cnt[e] += pos ? 1 : 0;
         }
     };
-    // four rows per trip: eight 16-byte loads in flight per thread; rows are still accumulated in their original order
+    auto fan_in = [&](long long row, const float4 d4) {
+        float4* q = reinterpret_cast<float4*>(p.dres + row * p.dres_ld + c);
+        float4 o = d4;
+        if (p.dres_acc) {
+            const float4 t = *q;
+            o = make_float4(t.x + d4.x, t.y + d4.y, t.z + d4.z, t.w + d4.w);
+        }
+        *q = o;
+    };
+    // four rows per trip, and the next trip's eight 16-byte loads are issued before this trip's rows are accumulated (two
+    // waves per SIMD cannot hide a memory round trip per trip otherwise); rows are accumulated in their original order
+    const long long trip = 4LL * rgn;
     long long r = r0 + rg;
-    for (; r + 3LL * rpp < r1; r += 4LL * rpp) {
-        float4 d4[4], a4[4];
+    float4 d4[2][4], a4[2][4];
+    auto load_trip = [&](int b, long long row) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            d4[u] = *reinterpret_cast<const float4*>(dy + (r + (long long)u * rpp) * dy_ld + c);
-            a4[u] = *reinterpret_cast<const float4*>(a + (r + (long long)u * rpp) * a_ld + c);
+            d4[b][u] = *reinterpret_cast<const float4*>(p.dy + (row + (long long)u * rgn) * p.dy_ld + c);
+            a4[b][u] = *reinterpret_cast<const float4*>(p.a + (row + (long long)u * rgn) * p.a_ld + c);
         }
+    };
+    auto use_trip = [&](int b, long long row) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) accumulate(d4[u], a4[u]);
+        for (int u = 0; u < 4; ++u) {
+            if (RES) fan_in(row + (long long)u * rgn, d4[b][u]);
+            accumulate(d4[b][u], a4[b][u]);
+        }
+    };
+    const long long ntrips = r + 3LL * rgn < r1 ? (r1 - 3LL * rgn - r + trip - 1) / trip : 0;   // trips with all four rows inside
+    if (ntrips > 0) {
+        load_trip(0, r);
+        long long t = 0;
+        for (; t + 2 < ntrips; t += 2) {
+            load_trip(1, r + trip);
+            use_trip(0, r);
+            load_trip(0, r + 2 * trip);
+            use_trip(1, r + trip);
+            r += 2 * trip;
+        }
+        if (t + 1 < ntrips) {
+            load_trip(1, r + trip);
+            use_trip(0, r);
+            use_trip(1, r + trip);
+            r += 2 * trip;
+        } else {
+            use_trip(0, r);
+            r += trip;
+        }
     }
-    for (; r < r1; r += rpp)
-        accumulate(*reinterpret_cast<const float4*>(dy + r * dy_ld + c), *reinterpret_cast<const float4*>(a + r * a_ld + c));
+    for (; r < r1; r += rgn) {
+        const float4 dd = *reinterpret_cast<const float4*>(p.dy + r * p.dy_ld + c);
+        if (RES) fan_in(r, dd);
+        accumulate(dd, *reinterpret_cast<const float4*>(p.a + r * p.a_ld + c));
+    }
     // order in memory: S0, S1, S2, S3, S4 (count), S5 (sum a)
-    double out[Y3_BNB_SUMS][4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        out[0][e] = acc[0][e];
-        out[1][e] = acc[1][e];
-        out[2][e] = acc[2][e];
-        out[3][e] = acc[3][e];
-        out[4][e] = (double)cnt[e];
-        out[5][e] = acc[4][e];
+        double* q = sm + tid * (4 * Y3_BNB_SUMS) + e;
+        q[0] = acc[0][e];
+        q[4] = acc[1][e];
+        q[8] = acc[2][e];
+        q[12] = acc[3][e];
+        q[16] = (double)cnt[e];
+        q[20] = acc[4][e];
     }
-#pragma unroll
-    for (int j = 0; j < Y3_BNB_SUMS; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sm[threadIdx.x * (4 * Y3_BNB_SUMS) + j * 4 + e] = out[j][e];
     __syncthreads();
-    if (rg == 0) {
-        for (int g = 1; g < rpp; ++g)
+    // sum the row groups (fixed order) with every thread busy: output o = (sum j, channel ch of the slice)
+    double* mine = p.partials + ((long long)slice * p.parts + part) * (Y3_BNB_SUMS * sw);
+    for (int o = tid; o < Y3_BNB_SUMS * sw; o += 256) {
+        const int j = o / sw, ch = o - j * sw;
+        const double* q = sm + (ch >> 2) * (4 * Y3_BNB_SUMS) + j * 4 + (ch & 3);
+        double s = q[0];
+        for (int g = 1; g < rgn; ++g) s += q[(long long)g * lc * (4 * Y3_BNB_SUMS)];
+        __hip_atomic_store(mine + o, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1: written through to where every XCD sees it
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(p.tickets + slice, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == p.parts - 1;
+        if (last) __hip_atomic_store(p.tickets + slice, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = last;
+    }
+    __syncthreads();
+    if (last_flag == 0) return;
+
+    // ---- the slice's last arrival: partials -> sums.  Thread = (channel pair, part lane); 16-byte sc1 loads, 12 in flight
+    // (256 workgroups of 32 channels: two parts per thread, one round trip).
+    const int half = sw >> 1, chp = tid % half, pl = tid / half, pln = 256 / half;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.partials + (long long)slice * p.parts * (Y3_BNB_SUMS * sw), 0,
+                                                                         (unsigned)(p.parts * Y3_BNB_SUMS * sw * 8), 0x00020000);
+    double t[Y3_BNB_SUMS][2];
+#pragma unroll
+    for (int j = 0; j < Y3_BNB_SUMS; ++j) t[j][0] = t[j][1] = 0.0;
+    const unsigned part_bytes = (unsigned)(Y3_BNB_SUMS * sw * 8);
+    int q = pl;
+    for (; q + pln < p.parts; q += 2 * pln) {
+        f32x4 v[2][Y3_BNB_SUMS];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int j = 0; j < Y3_BNB_SUMS; ++j)
+                v[u][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(q + u * pln) * part_bytes + (unsigned)(j * sw * 8 + chp * 16), 0, 16 /* sc1 */);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) out[j][e] += sm[(g * c4n + cq) * (4 * Y3_BNB_SUMS) + j * 4 + e];
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < Y3_BNB_SUMS; ++j) {
+                const double2 d = __builtin_bit_cast(double2, v[u][j]);
+                t[j][0] += d.x;
+                t[j][1] += d.y;
+            }
+    }
+    if (q < p.parts) {
 #pragma unroll
         for (int j = 0; j < Y3_BNB_SUMS; ++j) {
-            double* dst = reinterpret_cast<double*>(partials) + ((long long)blockIdx.x * Y3_BNB_SUMS + j) * C + c;
-            dst[0] = out[j][0];
-            dst[1] = out[j][1];
-            dst[2] = out[j][2];
-            dst[3] = out[j][3];
+            const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)q * part_bytes + (unsigned)(j * sw * 8 + chp * 16), 0, 16 /* sc1 */);
+            const double2 d = __builtin_bit_cast(double2, v);
+            t[j][0] += d.x;
+            t[j][1] += d.y;
         }
     }
-}
-
-extern "C" int y3_bn_bwd_reduce(const y3_tensor* dy, const y3_tensor* a, const float* save_mean, const float* save_rstd, float alpha,
-                                float* partials, int* nparts, y3_stream_t stream) {
-    (void)save_mean;
-    (void)save_rstd;
-    (void)alpha;   // raw moments: mean / rstd / slope enter in y3_bn_bwd_finalize
-    if (int e = check_view4(dy, "bn_bwd_reduce dy")) return e;
-    if (int e = check_view4(a, "bn_bwd_reduce a")) return e;
-    Y3_CHECK_ARG(same_geom(dy, a) && partials, "bn_bwd_reduce: geometry/pointers");
-    Y3_CHECK_ARG(a->c <= 1024 && 256 % (a->c / 4) == 0, "bn_bwd_reduce: channels %d unsupported (C/4 must divide 256, C <= 1024)", a->c);
-    const int parts = y3_bn_bwd_partials((int)pixels(a), a->c);
-    if (nparts) *nparts = parts;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, dy->ptr, dy->ld, a->ptr, a->ld, partials, pixels(a),
-                       a->c);
-    Y3_CHECK_LAUNCH("bn_bwd_reduce");
-    return Y3_OK;
-}
-
-// A block owns 4 channels: 128 partial-row lanes x 6 sums = 768 threads, each loading 4 doubles per row; C/4 blocks.
-__global__ __launch_bounds__(768) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, double count, float alpha,
-                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                              const float* __restrict__ rstd, float* dgamma, float* dbeta,
-                                                              float* dbias, float* coef) {
-    __shared__ double sm[Y3_BNB_SUMS][128][4];
-    const int j = threadIdx.x % Y3_BNB_SUMS, lane = threadIdx.x / Y3_BNB_SUMS;
-    const int c0 = blockIdx.x * 4;
-    const double* src = reinterpret_cast<const double*>(partials);
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int t = lane; t < nparts; t += 128) {
-        const double* p = src + ((long long)t * Y3_BNB_SUMS + j) * C + c0;
-        const double2 lo = *reinterpret_cast<const double2*>(p), hi = *reinterpret_cast<const double2*>(p + 2);
-        acc[0] += lo.x;
-        acc[1] += lo.y;
-        acc[2] += hi.x;
-        acc[3] += hi.y;
-    }
+    __syncthreads();      // the row-group sums in `sm` have been read by everybody
 #pragma unroll
-    for (int e = 0; e < 4; ++e) sm[j][lane][e] = acc[e];
+    for (int j = 0; j < Y3_BNB_SUMS; ++j) {
+        sm[(pl * Y3_BNB_SUMS + j) * sw + 2 * chp] = t[j][0];
+        sm[(pl * Y3_BNB_SUMS + j) * sw + 2 * chp + 1] = t[j][1];
+    }
     __syncthreads();
-    for (int half = 64; half >= 1; half >>= 1) {
-        if (lane < half)
+    if (tid < sw) {
+        double s[Y3_BNB_SUMS];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sm[j][lane][e] += sm[j][lane + half][e];
-        __syncthreads();
-    }
-    if (threadIdx.x < 4) {
-        const int e = threadIdx.x, c = c0 + e;
-        const double s0 = sm[0][0][e], s1 = sm[1][0][e], s2 = sm[2][0][e], s3 = sm[3][0][e], s4 = sm[4][0][e], s5 = sm[5][0][e];
-        const double ga = gamma[c], r = rstd[c], mu = mean[c], al = (double)alpha, inv_count = 1.0 / count;
-        const double db = s0;                                                    // sum dy
-        const double dg = r * (s1 - mu * s0);                                    // sum dy * xhat
-        const double sdys = al * s0 + (1.0 - al) * s2;                           // sum dy * slope
-        const double ss = al * count + (1.0 - al) * s4;                          // sum slope
-        const double sxs = r * ((1.0 - al) * (s3 - mu * s4) + al * (s5 - mu * count));   // sum xhat * slope
+        for (int j = 0; j < Y3_BNB_SUMS; ++j) {
+            s[j] = sm[j * sw + tid];
+            for (int g = 1; g < pln; ++g) s[j] += sm[(g * Y3_BNB_SUMS + j) * sw + tid];
+        }
+        const int cc = slice * sw + tid, C = p.C;
+        const double ga = p.gamma[cc], rr = p.rstd[cc], mu = p.mean[cc], al = (double)p.alpha, count = p.count, inv_count = 1.0 / count;
+        const double db = s[0];                                                       // sum dy
+        const double dg = rr * (s[1] - mu * s[0]);                                    // sum dy * xhat
+        const double sdys = al * s[0] + (1.0 - al) * s[2];                            // sum dy * slope
+        const double ss = al * count + (1.0 - al) * s[4];                             // sum slope
+        const double sxs = rr * ((1.0 - al) * (s[3] - mu * s[4]) + al * (s[5] - mu * count));   // sum xhat * slope
         // da = ga*r*(dy - db/M - xhat*dg/M);  dz = da*slope;  dbias = sum dz
-        dgamma[c] = (float)dg;
-        dbeta[c] = (float)db;
-        dbias[c] = (float)(ga * r * (sdys - db * inv_count * ss - dg * inv_count * sxs));
-        const double k1 = ga * r;
-        const double k2 = -ga * r * r * dg * inv_count;
-        const double k3 = -ga * r * db * inv_count - k2 * mu;
-        coef[c] = (float)k1;
-        coef[C + c] = (float)k2;
-        coef[2 * C + c] = (float)k3;
+        p.dgamma[cc] = (float)dg;
+        p.dbeta[cc] = (float)db;
+        p.dbias[cc] = (float)(ga * rr * (sdys - db * inv_count * ss - dg * inv_count * sxs));
+        const double k1 = ga * rr;
+        const double k2 = -ga * rr * rr * dg * inv_count;
+        const double k3 = -ga * rr * db * inv_count - k2 * mu;
+        p.coef[cc] = (float)k1;
+        p.coef[C + cc] = (float)k2;
+        p.coef[2 * C + cc] = (float)k3;
     }
 }
-extern "C" int y3_bn_bwd_finalize(const float* partials, int nparts, int c, int count, const float* gamma, const float* save_mean,
-                                  const float* save_rstd, float alpha, float* dgamma, float* dbeta, float* dbias, float* coef,
-                                  y3_stream_t stream) {
-    Y3_CHECK_ARG(partials && gamma && save_mean && save_rstd && dgamma && dbeta && dbias && coef, "bn_bwd_finalize: null pointer");
-    Y3_CHECK_ARG(nparts > 0 && c > 0 && count > 0, "bn_bwd_finalize: bad sizes");
-    Y3_CHECK_ARG((c & 3) == 0 && ((uintptr_t)partials & 15) == 0, "bn_bwd_finalize: channels must be a multiple of 4, partials 16-byte aligned");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c / 4), dim3(768), 0, (hipStream_t)stream, partials, nparts, c, (double)count, alpha, gamma,
-                       save_mean, save_rstd, dgamma, dbeta, dbias, coef);
-    Y3_CHECK_LAUNCH("bn_bwd_finalize");
+
+extern "C" int y3_bn_bwd_stats(const y3_tensor* dy, const y3_tensor* a, const y3_tensor* dres, int dres_accumulate, const float* gamma,
+                               const float* save_mean, const float* save_rstd, float alpha, float* dgamma, float* dbeta, float* dbias,
+                               float* coef, void* workspace, size_t workspace_bytes, y3_stream_t stream) {
+    if (int e = check_view4(dy, "bn_bwd_stats dy")) return e;
+    if (int e = check_view4(a, "bn_bwd_stats a")) return e;
+    Y3_CHECK_ARG(same_geom(dy, a), "bn_bwd_stats: dy / a geometry");
+    Y3_CHECK_ARG(gamma && save_mean && save_rstd && dgamma && dbeta && dbias && coef && workspace, "bn_bwd_stats: null pointer");
+    if (dres) {
+        if (int e = check_view4(dres, "bn_bwd_stats dres")) return e;
+        Y3_CHECK_ARG(same_geom(dy, dres), "bn_bwd_stats: dres geometry");
+    }
+    BnbPlan pl;
+    Y3_CHECK_ARG(plan_bnb(pixels(a), a->c, &pl), "bn_bwd_stats: channels %d unsupported (a multiple of 64 up to 1024, or 4 / 8 / 16 / 32)", a->c);
+    const size_t need = (size_t)Y3_BNB_TICKETS + (size_t)pl.parts * pl.slices * Y3_BNB_SUMS * pl.sw * sizeof(double);
+    Y3_CHECK_ARG(workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0, "bn_bwd_stats: workspace %zu bytes, %zu needed (16-byte aligned)",
+                 workspace_bytes, need);
+    BnbArgs p;
+    p.dy = dy->ptr; p.a = a->ptr; p.dres = dres ? dres->ptr : nullptr;
+    p.tickets = reinterpret_cast<int*>(workspace);
+    p.partials = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + Y3_BNB_TICKETS);
+    p.gamma = gamma; p.mean = save_mean; p.rstd = save_rstd;
+    p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = dbias; p.coef = coef;
+    p.npix = pixels(a); p.count = (double)pixels(a);
+    p.dy_ld = dy->ld; p.a_ld = a->ld; p.dres_ld = dres ? dres->ld : 0; p.dres_acc = dres_accumulate;
+    p.C = a->c; p.lc = pl.lc; p.slices = pl.slices; p.parts = pl.parts;
+    p.alpha = alpha;
+    if (dres)
+        hipLaunchKernelGGL(bn_bwd_stats_kernel<true>, dim3(pl.parts * pl.slices), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(bn_bwd_stats_kernel<false>, dim3(pl.parts * pl.slices), dim3(256), 0, (hipStream_t)stream, p);
+    Y3_CHECK_LAUNCH("bn_bwd_stats");
     return Y3_OK;
 }
 

@@ -53,9 +53,8 @@ SIGNATURES = {
     'y3_bn_fold_inference': (i32, [fp, fp, fp, fp, f32, i32, fp, fp, vp]),
     'y3_bn_fold_inference_batched': (i32, [fp, fp, fp, ip, i32, f32, vp]),
     'y3_bn_apply': (i32, [TP, fp, fp, TP, TP, vp]),
-    'y3_bn_bwd_reduce': (i32, [TP, TP, fp, fp, f32, fp, C.POINTER(C.c_int), vp]),
-    'y3_bn_bwd_partials': (i32, [i32, i32]),
-    'y3_bn_bwd_finalize': (i32, [fp, i32, i32, i32, fp, fp, fp, f32, fp, fp, fp, fp, vp]),
+    'y3_bn_bwd_stats': (i32, [TP, TP, TP, i32, fp, fp, fp, f32, fp, fp, fp, fp, vp, sz, vp]),
+    'y3_bn_bwd_workspace': (sz, [i32, i32]),
     'y3_bn_bwd_apply': (i32, [TP, TP, fp, f32, TP, vp]),
     'y3_upsample_sum2x_fwd': (i32, [TP, TP, vp]),
     'y3_upsample_sum2x_bwd': (i32, [TP, TP, vp]),

@@ -248,7 +248,8 @@ class _Plan:
                        mdl.fold_table().data_ptr(), mdl.fold_layers, BN_EPS)
         if tr:
             self.dz = torch.empty(max_mc, dtype=torch.float32, device=dev)
-            self.bnb_ws = torch.empty(512 * 6 * 1024, dtype=torch.float64, device=dev)      # y3_bn_bwd_partials() <= 512 rows of 6 x C doubles, C <= 1024
+            # y3_bn_bwd_workspace(): 1 KiB of tickets (zero before the first launch) + <= 512 x 6 x 64 fp64 partials
+            self.bnb_ws = torch.zeros(1024 + 512 * 6 * 64 * 8, dtype=torch.uint8, device=dev)
             self.wg_ws_bytes = 0
 
         def ptr(off):
@@ -461,17 +462,19 @@ class _Plan:
                 sp = specs[i]
                 assert y.gw, 'gradient of layer %d output never produced' % i
                 dy = y.grad
-                if resid is not None:                       # out = resid + y  ->  d resid += d out
+                dr = None
+                if resid is not None:                       # out = resid + y  ->  d resid += d out, fused into the pass that reads dy anyway
                     dr = self._grad_of(resid)
-                    self._emit(self.bwd, lib.y3_add_inplace if resid.gw else lib.y3_copy, dy.v, dr.v)
+                    dr_acc = 1 if resid.gw else 0
                     resid.mark_written()
                 slot = nconv % len(dz_bufs)
                 nconv += 1
                 dz = _T(dz_bufs[slot], a.n, a.h, a.w, sp.cout)
                 self.keep.append(dz)
-                self._emit(self.bwd, lib.y3_bn_bwd_reduce, dy.v, a.v, smean, srstd, LRELU_ALPHA, self.bnb_ws.data_ptr(), None)
-                self._emit(self.bwd, lib.y3_bn_bwd_finalize, self.bnb_ws.data_ptr(), lib.y3_bn_bwd_partials(a.m, sp.cout), sp.cout, a.m,
-                           mdl.params.data_ptr() + 4 * sp.g_off, smean, srstd, LRELU_ALPHA, gptr(sp.g_off), gptr(sp.be_off), gptr(sp.b_off), coef)
+                assert int(lib.y3_bn_bwd_workspace(a.m, sp.cout)) <= self.bnb_ws.numel()
+                self._emit(self.bwd, lib.y3_bn_bwd_stats, dy.v, a.v, dr.v if dr is not None else None, dr_acc if dr is not None else 0,
+                           mdl.params.data_ptr() + 4 * sp.g_off, smean, srstd, LRELU_ALPHA, gptr(sp.g_off), gptr(sp.be_off), gptr(sp.b_off), coef,
+                           self.bnb_ws.data_ptr(), self.bnb_ws.numel())
                 if two and dz_busy[slot] is not None:
                     self.bwd.append(('main_wait', dz_busy[slot]))
                 self._emit(self.bwd, lib.y3_bn_bwd_apply, dy.v, a.v, coef, LRELU_ALPHA, dz.v)

@@ -233,10 +233,12 @@ def test_conv_fwd_detection_head(hip, shape):
     dld = 16
     dbuf, dv = nhwc_buf(n, h, w, cout, ld=dld)
     wd, bd = wk.contiguous().cuda(), b.cuda()
+    wsb = int(hip.lib.y3_conv2d_fwd_workspace(n * h * w, cin, 1, cout))      # the heads split K: few output columns, long K
+    ws = torch.zeros(max(wsb, 16), dtype=torch.uint8, device='cuda')
     for flags, ref in ((0, _conv_ref(x, wk, b, 1, 1)), (hip.EPI_LRELU, F.leaky_relu(_conv_ref(x, wk, b, 1, 1), 0.2))):
         dbuf.fill_(float('nan'))
         hip.check(hip.lib.y3_conv2d_fwd(hip.Tensor(sv.data_ptr(), n, h, w, cin, cin), wd.data_ptr(), bd.data_ptr(), 1, 1,
-                                        hip.Tensor(dv.data_ptr(), n, h, w, cout, dld), flags, 0.2, None, None, None, None, None, 0, stream()))
+                                        hip.Tensor(dv.data_ptr(), n, h, w, cout, dld), flags, 0.2, None, None, None, None, ws.data_ptr(), wsb, stream()))
         assert_close(dv.cpu().permute(0, 3, 1, 2), ref, rtol=2e-5, what='head conv')
         if dld > cout:
             assert torch.isnan(dbuf.view(-1, dld)[:, cout:]).all()
@@ -320,9 +322,9 @@ def test_conv_wgrad(hip, case):
     assert_close(dw.cpu(), wk.grad, rtol=5e-5, what='wgrad')
 
 
-@pytest.mark.parametrize('shape', [(2, 13, 13, 64), (8, 52, 52, 128), (1, 104, 104, 32), (2, 7, 9, 1024)])
+@pytest.mark.parametrize('shape', [(2, 13, 13, 64), (8, 52, 52, 128), (1, 104, 104, 32), (2, 7, 9, 1024), (2, 26, 26, 512), (2, 208, 208, 64), (8, 52, 52, 256)])
 def test_batchnorm_train_fwd_bwd(hip, shape):
-    """stats finalize + apply + backward (reduce / finalize / apply) vs fp64 autograd of BN(lrelu(z))."""
+    """stats finalize + apply + backward (stats with the in-launch finalize + fused residual fan-in, apply) vs fp64 autograd of BN(lrelu(z))."""
     from util import nhwc_buf, stream, assert_close
     n, h, w, c = shape
     g = torch.Generator().manual_seed(17)
@@ -363,14 +365,25 @@ def test_batchnorm_train_fwd_bwd(hip, shape):
     _, dyv = nhwc_buf(n, h, w, c, ld=c + 4)
     dyv.copy_(dy)
     DY = hip.Tensor(dyv.data_ptr(), n, h, w, c, c + 4)
-    parts = hip.lib.y3_bn_bwd_partials(M, c)
-    pws = torch.empty(parts * 6 * c, device='cuda', dtype=torch.float64)
-    npart = C.c_int(0)
-    hip.check(hip.lib.y3_bn_bwd_reduce(DY, A, smean.data_ptr(), srstd.data_ptr(), 0.2, pws.data_ptr(), C.byref(npart), stream()))
-    assert npart.value == parts
+    ws_bytes = int(hip.lib.y3_bn_bwd_workspace(M, c))
+    assert ws_bytes > 1024
+    pws = torch.zeros(ws_bytes, device='cuda', dtype=torch.uint8)       # tickets zero before the first launch
     dg, db, dbias, coef = torch.empty(c, device='cuda'), torch.empty(c, device='cuda'), torch.empty(c, device='cuda'), torch.empty(3 * c, device='cuda')
-    hip.check(hip.lib.y3_bn_bwd_finalize(pws.data_ptr(), parts, c, M, gd.data_ptr(), smean.data_ptr(), srstd.data_ptr(), 0.2, dg.data_ptr(),
-                                         db.data_ptr(), dbias.data_ptr(), coef.data_ptr(), stream()))
+    # the residual fan-in rides along: dres = dy on the first launch, dres += dy on the second (which also proves the
+    # tickets were left at zero and that the sums do not depend on which workgroup finishes last)
+    _, drv = nhwc_buf(n, h, w, c, ld=c + 12)
+    DR = hip.Tensor(drv.data_ptr(), n, h, w, c, c + 12)
+    outs = []
+    for acc in (0, 1):
+        hip.check(hip.lib.y3_bn_bwd_stats(DY, A, DR, acc, gd.data_ptr(), smean.data_ptr(), srstd.data_ptr(), 0.2, dg.data_ptr(), db.data_ptr(),
+                                          dbias.data_ptr(), coef.data_ptr(), pws.data_ptr(), ws_bytes, stream()))
+        outs.append(torch.cat([dg, db, dbias, coef]).cpu())
+    assert torch.equal(outs[0], outs[1]), 'bn_bwd_stats is not reproducible'
+    assert torch.equal(drv.cpu(), 2 * dyv.cpu()), 'fused residual fan-in'
+    assert int(pws[:1024].view(torch.int32).abs().sum()) == 0, 'tickets not reset'
+    hip.check(hip.lib.y3_bn_bwd_stats(DY, A, None, 0, gd.data_ptr(), smean.data_ptr(), srstd.data_ptr(), 0.2, dg.data_ptr(), db.data_ptr(),
+                                      dbias.data_ptr(), coef.data_ptr(), pws.data_ptr(), ws_bytes, stream()))
+    assert torch.equal(torch.cat([dg, db, dbias, coef]).cpu(), outs[0])
     _, dzv = nhwc_buf(n, h, w, c)
     hip.check(hip.lib.y3_bn_bwd_apply(DY, A, coef.data_ptr(), 0.2, hip.Tensor(dzv.data_ptr(), n, h, w, c, c), stream()))
     assert_close(dg.cpu(), gamma.grad, rtol=1e-4, what='dgamma')

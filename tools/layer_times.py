@@ -66,5 +66,15 @@ for r in rows:
 print('%-6s %8s %5s %5s k s  cnt   total_us   avg_us  TFLOP/s' % ('kind', 'M', 'cin', 'cout'))
 for key, d in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print('%-6s %8d %5d %5d %d %d %4d %10.1f %8.1f %8.1f' % (*key, d[0], d[1], d[1] / d[0], d[2] / d[1] / 1e6))
+# the streaming kernels, per tensor shape (first argument is the tensor they walk)
+other = {}
+for i, (nm, args, a, b) in enumerate(recs):
+    if nm.startswith('y3_bn') and hasattr(args[0], 'ld'):
+        t0 = args[0]
+        d = other.setdefault((nm, t0.n * t0.h * t0.w, t0.c), [0, 0.0])
+        d[0] += 1
+        d[1] += best[i]
+for key, d in sorted(other.items(), key=lambda kv: (kv[0][0], -kv[1][1])):
+    print('%-20s M=%8d C=%5d cnt %3d total_us %8.1f avg_us %7.1f  %6.0f GB/s of tensor' % (*key, d[0], d[1], d[1] / d[0], key[1] * key[2] * 4 / (d[1] / d[0]) / 1e3))
 print('totals (us):', {k: round(v, 1) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])})
 print('sum all us', sum(tot.values()))
