@@ -269,6 +269,31 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
 // invariant; padding / tile-edge lanes are pointed past the descriptor's range and read zeros from the
 // hardware bounds check instead of branching.
 // ---------------------------------------------------------------------------
+// x / d for 0 <= x < 2^31 without a divide: the compiler's sequence for a run-time divisor is ~30 dependent instructions
+// (float reciprocal + two correction steps), and the index decode of a workgroup needs five of them before its first load.
+//   d == 1: mul == 0 (identity);  d == 2^k: shift = k - 1, mul = 2^31 + 1;  else shift = floor(log2 d), mul = floor(2^(32+shift) / d) + 1
+// (error term mul * d - 2^(32+shift) <= d, so floor is exact while x * d < 2^(32+shift), i.e. for every x < 2^31).
+struct Y3Div {
+    unsigned mul;
+    int shift;
+};
+static Y3Div y3_make_div(int d) {
+    Y3Div r = {0u, 0};
+    if (d <= 1) return r;
+    int s = 0;
+    while ((2LL << s) <= d) ++s;      // floor(log2 d)
+    if ((1LL << s) == d) {
+        r.shift = s - 1;
+        r.mul = 0x80000001u;
+    } else {
+        r.shift = s;
+        r.mul = (unsigned)(((1ULL << (32 + s)) / (unsigned long long)d) + 1ULL);
+    }
+    return r;
+}
+__device__ __forceinline__ int y3_div(int x, const Y3Div d) { return d.mul ? (int)(__umulhi((unsigned)x, d.mul) >> d.shift) : x; }
+#define Y3_PIN_S(x) asm volatile("" : "+s"(x))
+
 struct FastArgs {
     const float* src;  // biased so that every tap offset is >= 0
     const float* wt;
@@ -292,6 +317,10 @@ struct FastArgs {
     unsigned flags;
     float alpha;
     int nbn, nbm, col_major;
+    // divisions of the index decode as multiply-high + shift (y3_make_div): tile id by the fastest-varying tile count, work
+    // item by the slice counts, output pixel by OH*OW and by OW
+    int nb_fast, ohw;
+    Y3Div dv_nb, dv_s0, dv_s1, dv_ohw, dv_ow;
     // Split-K with the reduction inside the kernel.  Work items: tiles [0, sk_f) are cut into sk_s0 K slices each, tiles
     // [sk_f, tiles) into sk_s1 (the remainder of a launch whose tile count is not a multiple of the CU count is split
     // finer so that every CU ends up with the same amount of MFMA work).  Item i < sk_n0 = sk_f * sk_s0 is slice
@@ -342,7 +371,7 @@ __device__ __forceinline__ void y3_sgb_pairs() {   // COUNT x { MFMAS matrix ins
 }
 
 template <int BM, int BN, int WM, int WN, int BK, bool DENSE, int PIPE = 0>
-__device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int bid0) {
+__device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw, const int grid) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int LDA = BK + 4;
     constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
@@ -367,31 +396,49 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int bid0
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
+    // Every scalar of the index decode is fetched from the argument segment HERE, in one batch (the pins keep the compiler from
+    // sinking each load to its first use): left alone it emitted ~17 load / wait / branch rounds of ~200 cycles each before
+    // the first global load of the workgroup was issued.
+    int sk_n0 = p.sk_n0, sk_s0 = p.sk_s0, sk_s1 = p.sk_s1, sk_f = p.sk_f, sk_c0 = p.sk_chunk0, sk_c1 = p.sk_chunk1;
+    int col_major = p.col_major, nb_fast = p.nb_fast, ohw = p.ohw, OW = p.OW, aK = p.K, aM = p.M, aH = p.H, aW = p.W;
+    int src_ld = p.src_ld, csh = p.sh, csw = p.sw, ntaps = p.ntaps, Nout = p.Nout;
+    unsigned dnb_m = p.dv_nb.mul, ds0_m = p.dv_s0.mul, ds1_m = p.dv_s1.mul, dohw_m = p.dv_ohw.mul, dow_m = p.dv_ow.mul;
+    int dnb_s = p.dv_nb.shift, ds0_s = p.dv_s0.shift, ds1_s = p.dv_s1.shift, dohw_s = p.dv_ohw.shift, dow_s = p.dv_ow.shift;
+    Y3_PIN_S(sk_n0); Y3_PIN_S(sk_s0); Y3_PIN_S(sk_s1); Y3_PIN_S(sk_f); Y3_PIN_S(sk_c0); Y3_PIN_S(sk_c1);
+    Y3_PIN_S(col_major); Y3_PIN_S(nb_fast); Y3_PIN_S(ohw); Y3_PIN_S(OW); Y3_PIN_S(aK); Y3_PIN_S(aM); Y3_PIN_S(aH); Y3_PIN_S(aW);
+    Y3_PIN_S(src_ld); Y3_PIN_S(csh); Y3_PIN_S(csw); Y3_PIN_S(ntaps); Y3_PIN_S(Nout);
+    Y3_PIN_S(dnb_m); Y3_PIN_S(ds0_m); Y3_PIN_S(ds1_m); Y3_PIN_S(dohw_m); Y3_PIN_S(dow_m);
+    Y3_PIN_S(dnb_s); Y3_PIN_S(ds0_s); Y3_PIN_S(ds1_s); Y3_PIN_S(dohw_s); Y3_PIN_S(dow_s);
+    const Y3Div dv_nb = {dnb_m, dnb_s}, dv_s0 = {ds0_m, ds0_s}, dv_s1 = {ds1_m, ds1_s}, dv_ohw = {dohw_m, dohw_s}, dv_ow = {dow_m, dow_s};
+
+    // work item: ids are contiguous per XCD inside the two ranges [0, sk_n0) and [sk_n0, grid)
+    const int bid0 = braw < sk_n0 ? y3_xcd_remap(braw, sk_n0) : sk_n0 + y3_xcd_remap(braw - sk_n0, grid - sk_n0);
     int bid, kz, nz, kchunk;
-    if (bid0 < p.sk_n0) {
-        bid = bid0 / p.sk_s0;
-        kz = bid0 - bid * p.sk_s0;
-        nz = p.sk_s0;
-        kchunk = p.sk_chunk0;
+    if (bid0 < sk_n0) {
+        bid = y3_div(bid0, dv_s0);
+        kz = bid0 - bid * sk_s0;
+        nz = sk_s0;
+        kchunk = sk_c0;
     } else {
-        const int t = bid0 - p.sk_n0;
-        const int q = t / p.sk_s1;
-        bid = p.sk_f + q;
-        kz = t - q * p.sk_s1;
-        nz = p.sk_s1;
-        kchunk = p.sk_chunk1;
+        const int t = bid0 - sk_n0;
+        const int q = y3_div(t, dv_s1);
+        bid = sk_f + q;
+        kz = t - q * sk_s1;
+        nz = sk_s1;
+        kchunk = sk_c1;
     }
     // tile id -> (row tile, column tile).  Ids are contiguous per XCD (y3_xcd_remap), so the fastest-varying coordinate decides
     // which operand an XCD's private 4 MB L2 keeps: row-major ids walk all column tiles of a few row tiles (the activation
     // rows stay, the whole kernel matrix streams through once per row tile), column-major ids walk all row tiles of a few
     // column tiles (a slice of the kernel matrix stays, the activations stream).  The host picks column-major when the kernel
     // matrix is too large to stay resident (> 2 MB): 13x13 512->1024 3x3 fetched its 18.9 MB of weights ~24 times per launch.
-    const int bm = p.col_major ? bid % p.nbm : bid / p.nbn;
-    const int bn = p.col_major ? bid / p.nbm : bid % p.nbn;
+    // nb_fast is the count of the fastest-varying coordinate (nbm when column-major, else nbn).
+    const int tq = y3_div(bid, dv_nb), tr = bid - tq * nb_fast;
+    const int bm = col_major ? tr : tq;
+    const int bn = col_major ? tq : tr;
     const int m0 = bm * BM, n0 = bn * BN;
-    const int ohw = p.OH * p.OW;
     const int kbeg = kz * kchunk * BK;
-    const int kend = min(p.K, kbeg + kchunk * BK);
+    const int kend = min(aK, kbeg + kchunk * BK);
 
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.wt_bytes, 0x00020000);
@@ -403,18 +450,19 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int bid0
     for (int i = 0; i < A_LOADS; ++i) {
         const int row = (tid + i * THREADS) / KV;
         const int m = m0 + row;
-        const bool ok = m < p.M;
+        const bool ok = m < aM;
         const int mm = ok ? m : 0;
-        const int n = mm / ohw;
+        const int n = y3_div(mm, dv_ohw);
         const int r = mm - n * ohw;
-        const int oh = r / p.OW;
-        const int ow = r - oh * p.OW;
-        const int ih0 = oh * p.sh, iw0 = ow * p.sw;
-        a_voff[i] = (unsigned)(((n * p.H + ih0) * p.W + iw0) * p.src_ld + a_kv * 4) * 4u;
+        const int oh = y3_div(r, dv_ow);
+        const int ow = r - oh * OW;
+        const int ih0 = oh * csh, iw0 = ow * csw;
+        a_voff[i] = (unsigned)(((n * aH + ih0) * aW + iw0) * src_ld + a_kv * 4) * 4u;
         unsigned msk = 0;
-        for (int t = 0; t < p.ntaps; ++t) {
+        // (decoding the taps from a packed 64-bit scalar instead of these two table loads per tap made the 3x3 layers 8 % slower: measured)
+        for (int t = 0; t < ntaps; ++t) {
             const int ih = ih0 + p.tap_dh[t], iw = iw0 + p.tap_dw[t];
-            if (ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) msk |= 1u << t;
+            if (ok && (unsigned)ih < (unsigned)aH && (unsigned)iw < (unsigned)aW) msk |= 1u << t;
         }
         a_mask[i] = msk;
     }
@@ -423,7 +471,7 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int bid0
     for (int i = 0; i < B_LOADS; ++i) {
         const int idx = tid + i * THREADS;
         const int kr = idx / BN4, n = n0 + (idx % BN4) * 4;
-        b_voff[i] = (idx < B_TOTAL && n < p.Nout) ? (unsigned)(kr * p.Nout + n) * 4u : Y3_OOB;
+        b_voff[i] = (idx < B_TOTAL && n < Nout) ? (unsigned)(kr * Nout + n) * 4u : Y3_OOB;
     }
 
     f32x4 ra[A_LOADS], rb[B_LOADS];
@@ -802,10 +850,10 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int bid0
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int mm = m < p.M ? m : 0;
-                const int nimg = mm / ohw;
+                const int nimg = y3_div(mm, dv_ohw);
                 const int rr = mm - nimg * ohw;
-                const int oh = rr / p.OW;
-                const int ow = rr - oh * p.OW;
+                const int oh = y3_div(rr, dv_ow);
+                const int ow = rr - oh * OW;
                 const unsigned pix = (unsigned)((nimg * p.DH + oh * p.dsh + p.doh) * p.DW + ow * p.dsw + p.dow);
                 rowpix[i][r] = m < p.M ? pix : 0xffffffffu;
             }
@@ -865,8 +913,7 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int bid0
 
 template <int BM, int BN, int WM, int WN, int BK, bool DENSE, int PIPE>
 __global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_kernel(const FastArgs p) {
-    const int b = blockIdx.x;
-    conv_fast_body<BM, BN, WM, WN, BK, DENSE, PIPE>(p, b < p.sk_n0 ? y3_xcd_remap(b, p.sk_n0) : p.sk_n0 + y3_xcd_remap(b - p.sk_n0, (int)gridDim.x - p.sk_n0));
+    conv_fast_body<BM, BN, WM, WN, BK, DENSE, PIPE>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Up to four independent gather-GEMMs in ONE launch: the (row parity, column parity) classes of a stride-2 data gradient.
@@ -881,7 +928,7 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_multi_kernel(
     int c = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i) c += ((int)blockIdx.x >= m.first[i]) ? 1 : 0;
-    conv_fast_body<BM, BN, WM, WN, BK, false, 2>(m.a[c], y3_xcd_remap((int)blockIdx.x - m.first[c], m.first[c + 1] - m.first[c]));
+    conv_fast_body<BM, BN, WM, WN, BK, false, 2>(m.a[c], (int)blockIdx.x - m.first[c], m.first[c + 1] - m.first[c]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1471,6 +1518,9 @@ static bool make_fast(const ConvArgs& a, int ntaps, int bk, FastArgs* f) {
         p.tap_wrow[t] = (int)((a.tap_wsel >> (4 * t)) & 15ull) * a.C;
     }
     p.ntaps = ntaps;
+    p.ohw = a.OH * a.OW;
+    p.dv_ohw = y3_make_div(p.ohw);
+    p.dv_ow = y3_make_div(a.OW);
     {
         // the tap list as a (rows x nx) grid: nx = length of the first run of equal dh
         int nx = 1;
@@ -1549,6 +1599,10 @@ static int launch_igemm(const ConvArgs& a, void* workspace, size_t workspace_byt
         f.nbm = y3_cdiv(p.M, t.bm);
         static const int colmajor_kb = env_int("Y3_COLMAJOR_KB", 2048);     // kernel matrix larger than this: column-major tile ids
         f.col_major = ((long long)p.K * p.Nout * 4 > (long long)colmajor_kb * 1024) ? 1 : 0;
+        f.nb_fast = f.col_major ? f.nbm : f.nbn;
+        f.dv_nb = y3_make_div(f.nb_fast);
+        f.dv_s0 = y3_make_div(pl.s0);
+        f.dv_s1 = y3_make_div(pl.s1);
         f.sk_f = pl.f;
         f.sk_s0 = pl.s0;
         f.sk_s1 = pl.s1;
@@ -1704,6 +1758,9 @@ static bool launch_dgrad_multi(const ConvArgs* cls, int ncls, hipStream_t st) {
         m.a[c].nbn = y3_cdiv(cls[c].Nout, t.bn);
         m.a[c].nbm = y3_cdiv(cls[c].M, t.bm);
         m.a[c].col_major = 0;
+        m.a[c].nb_fast = m.a[c].nbn;
+        m.a[c].dv_nb = y3_make_div(m.a[c].nbn);
+        m.a[c].dv_s0 = m.a[c].dv_s1 = y3_make_div(1);
         m.a[c].sk_f = m.a[c].sk_n0 = y3_cdiv(cls[c].M, t.bm) * m.a[c].nbn;   // whole tiles only
         m.a[c].sk_s0 = m.a[c].sk_s1 = 1;
         m.a[c].sk_chunk0 = m.a[c].sk_chunk1 = cls[c].K / t.bk;

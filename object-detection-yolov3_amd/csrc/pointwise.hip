@@ -278,26 +278,30 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const BnbArgs p) {
         }
         *q = o;
     };
-    // four rows per trip, and the next trip's eight 16-byte loads are issued before this trip's rows are accumulated (two
-    // waves per SIMD cannot hide a memory round trip per trip otherwise); rows are accumulated in their original order
+    // four rows per trip, and the next trip's eight 16-byte loads are issued before this trip's rows are accumulated (one
+    // wave per SIMD cannot hide a memory round trip per trip otherwise).  Rows past the band read as zeros, which leave every
+    // sum unchanged -- no serial remainder loop.  Rows are accumulated in their original order.
     const long long trip = 4LL * rgn;
     long long r = r0 + rg;
     float4 d4[2][4], a4[2][4];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_trip = [&](int b, long long row) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            d4[b][u] = *reinterpret_cast<const float4*>(p.dy + (row + (long long)u * rgn) * p.dy_ld + c);
-            a4[b][u] = *reinterpret_cast<const float4*>(p.a + (row + (long long)u * rgn) * p.a_ld + c);
+            const long long ru = row + (long long)u * rgn;
+            const bool in = ru < r1;
+            d4[b][u] = in ? *reinterpret_cast<const float4*>(p.dy + ru * p.dy_ld + c) : zero4;
+            a4[b][u] = in ? *reinterpret_cast<const float4*>(p.a + ru * p.a_ld + c) : zero4;
         }
     };
     auto use_trip = [&](int b, long long row) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (RES) fan_in(row + (long long)u * rgn, d4[b][u]);
+            if (RES && row + (long long)u * rgn < r1) fan_in(row + (long long)u * rgn, d4[b][u]);
             accumulate(d4[b][u], a4[b][u]);
         }
     };
-    const long long ntrips = r + 3LL * rgn < r1 ? (r1 - 3LL * rgn - r + trip - 1) / trip : 0;   // trips with all four rows inside
+    const long long ntrips = r < r1 ? (r1 - r + trip - 1) / trip : 0;
     if (ntrips > 0) {
         load_trip(0, r);
         long long t = 0;
@@ -312,16 +316,9 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const BnbArgs p) {
             load_trip(1, r + trip);
             use_trip(0, r);
             use_trip(1, r + trip);
-            r += 2 * trip;
         } else {
             use_trip(0, r);
-            r += trip;
         }
-    }
-    for (; r < r1; r += rgn) {
-        const float4 dd = *reinterpret_cast<const float4*>(p.dy + r * p.dy_ld + c);
-        if (RES) fan_in(r, dd);
-        accumulate(dd, *reinterpret_cast<const float4*>(p.a + r * p.a_ld + c));
     }
     // order in memory: S0, S1, S2, S3, S4 (count), S5 (sum a)
 #pragma unroll
