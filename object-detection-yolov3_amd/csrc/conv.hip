@@ -948,6 +948,8 @@ struct WgradArgs {
     unsigned src_bytes, dd_bytes;  // extents for the buffer descriptors (out-of-range lanes read zeros)
     int* tickets;  // splits > 1: one per (k-tile, n-tile), zero before the launch; `out` is then the slab area
     float* dw;     // final destination [K][Nout]
+    int ohw, ntaps;
+    Y3Div dv_tiles, dv_nbn, dv_ohw, dv_ow;   // index decode without run-time divides (y3_make_div)
 };
 
 #define Y3_WG_TABLE 2048   // pixels per split the LDS pixel table holds (plan_wgrad keeps chunks below it)
@@ -973,20 +975,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(const WgradArg
     // L lands on XCD L % 8: give every XCD whole pixel chunks (split = 8 * group + xcd) and let it walk all the
     // (k-tile, n-tile) pairs of that chunk, so the chunk's activations / gradients are fetched into ONE L2 instead of eight.
     // (With few chunks that idles XCDs or loses to the tile-major order, measured: then tiles are spread with the usual remap instead.)
+    // the scalars of the index decode, fetched from the argument segment in one batch (see conv_fast_body)
+    int splits = p.splits, tiles = p.tiles, nbn = p.nbn, chunk = p.chunk, aM = p.M, ohw = p.ohw, OW = p.OW, aH = p.H, aW = p.W;
+    int src_ld = p.src_ld, csh = p.sh, csw = p.sw, ntaps = p.ntaps;
+    unsigned dt_m = p.dv_tiles.mul, dn_m = p.dv_nbn.mul, dohw_m = p.dv_ohw.mul, dow_m = p.dv_ow.mul;
+    int dt_s = p.dv_tiles.shift, dn_s = p.dv_nbn.shift, dohw_s = p.dv_ohw.shift, dow_s = p.dv_ow.shift;
+    unsigned dhdw_lo = (unsigned)p.tap_dhdw, dhdw_hi = (unsigned)(p.tap_dhdw >> 32);
+    Y3_PIN_S(splits); Y3_PIN_S(tiles); Y3_PIN_S(nbn); Y3_PIN_S(chunk); Y3_PIN_S(aM); Y3_PIN_S(ohw); Y3_PIN_S(OW); Y3_PIN_S(aH); Y3_PIN_S(aW);
+    Y3_PIN_S(src_ld); Y3_PIN_S(csh); Y3_PIN_S(csw); Y3_PIN_S(ntaps);
+    Y3_PIN_S(dt_m); Y3_PIN_S(dn_m); Y3_PIN_S(dohw_m); Y3_PIN_S(dow_m); Y3_PIN_S(dt_s); Y3_PIN_S(dn_s); Y3_PIN_S(dohw_s); Y3_PIN_S(dow_s);
+    Y3_PIN_S(dhdw_lo); Y3_PIN_S(dhdw_hi);
+    const Y3Div dv_tiles = {dt_m, dt_s}, dv_nbn = {dn_m, dn_s}, dv_ohw = {dohw_m, dohw_s}, dv_ow = {dow_m, dow_s};
+    const unsigned long long tap_dhdw = ((unsigned long long)dhdw_hi << 32) | dhdw_lo;
     int split, bid;
-    if (p.splits >= 32) {
+    if (splits >= 32) {
         const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-        split = (jx / p.tiles) * 8 + xcd;
-        bid = jx % p.tiles;
+        const int q = y3_div(jx, dv_tiles);
+        split = q * 8 + xcd;
+        bid = jx - q * tiles;
     } else {
-        split = blockIdx.x / p.tiles;
-        bid = y3_xcd_remap(blockIdx.x % p.tiles, p.tiles);
+        split = y3_div((int)blockIdx.x, dv_tiles);
+        bid = y3_xcd_remap((int)blockIdx.x - split * tiles, tiles);
     }
-    if (split >= p.splits) return;
-    const int bk = bid / p.nbn, bn = bid % p.nbn;
+    if (split >= splits) return;
+    const int bk = y3_div(bid, dv_nbn), bn = bid - bk * nbn;
     const int k0 = bk * BKR, n0 = bn * BN;
-    const int mbeg = split * p.chunk;
-    const int mend = min(p.M, mbeg + p.chunk);
+    const int mbeg = split * chunk;
+    const int mend = min(aM, mbeg + chunk);
     const int nsteps = (mend > mbeg) ? (mend - mbeg + BP - 1) / BP : 0;
 
     // Pixel table: the (image, row, column) decomposition of every pixel of the split and the zero-padding test of every
@@ -994,21 +1009,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(const WgradArg
     // whose per-lane offset points past the descriptor's range whenever the element does not exist (padding, pixels beyond
     // the split, K / Nout tails): the hardware returns zeros, the loop has no branches and no 64-bit address arithmetic.
     {
-        const int ohw = p.OH * p.OW;
-        const int ntaps = p.K >> (p.logC > 30 ? 30 : p.logC) > 0 ? (p.logC > 30 ? 1 : p.K >> p.logC) : 1;
         for (int pl = tid; pl < nsteps * BP; pl += THREADS) {
             const int m = mbeg + pl;
             unsigned off = 0, msk = 0;
             if (m < mend) {
-                const int n = m / ohw;
+                const int n = y3_div(m, dv_ohw);
                 const int r = m - n * ohw;
-                const int oh = r / p.OW, ow = r - oh * p.OW;
-                const int ih0 = oh * p.sh, iw0 = ow * p.sw;
-                off = (unsigned)(((n * p.H + ih0) * p.W + iw0) * p.src_ld) * 4u;
+                const int oh = y3_div(r, dv_ow), ow = r - oh * OW;
+                const int ih0 = oh * csh, iw0 = ow * csw;
+                off = (unsigned)(((n * aH + ih0) * aW + iw0) * src_ld) * 4u;
                 for (int t = 0; t < ntaps; ++t) {
-                    const int code = (int)((p.tap_dhdw >> (4 * t)) & 15ull);
+                    const int code = (int)((tap_dhdw >> (4 * t)) & 15ull);
                     const int ih = ih0 + (code & 3) - 1, iw = iw0 + (code >> 2) - 1;
-                    if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) msk |= 1u << t;
+                    if ((unsigned)ih < (unsigned)aH && (unsigned)iw < (unsigned)aW) msk |= 1u << t;
                 }
             }
             pix[pl] = make_uint2(off, msk);
@@ -1022,7 +1035,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(const WgradArg
     const bool ak_ok = ak < p.K;            // K % 4 == 0 (Cin % 4 == 0): a quad is inside K or outside as a whole
     const int atap = ak_ok ? (ak >> p.logC) : 0;
     const int ac = ak & p.cmask;
-    const int acode = (int)((p.tap_dhdw >> (4 * atap)) & 15ull);
+    const int acode = (int)((tap_dhdw >> (4 * atap)) & 15ull);
     const int a_tapoff = ((((acode & 3) - 1) * p.W + ((acode >> 2) - 1)) * p.src_ld + ac) * 4;   // may be negative; only used where the tap is valid
     const unsigned a_bit = ak_ok ? 1u << atap : 0u;
     const int a_pp0 = tid / KR4;
@@ -1971,6 +1984,12 @@ extern "C" int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int 
     const WgradPlan w = plan_wgrad(p.K, p.Nout, p.M);
     p.chunk = w.chunk;
     p.nbn = y3_cdiv(p.Nout, w.bn);
+    p.ohw = OH * OW;
+    p.ntaps = taps;
+    p.dv_tiles = y3_make_div(w.tiles);
+    p.dv_nbn = y3_make_div(p.nbn);
+    p.dv_ohw = y3_make_div(p.ohw);
+    p.dv_ow = y3_make_div(OW);
     const size_t need = wgrad_ws_bytes(w, p.K, p.Nout);
     Y3_CHECK_ARG(workspace_bytes >= need && (need == 0 || workspace), "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
     Y3_CHECK_ARG(need < 0x7ff00000ull, "conv2d_wgrad: slab area too large (%zu bytes)", need);
