@@ -10,27 +10,36 @@ import sys
 FAMILY = ('conv_igemm', 'conv_wgrad', 'splitk_epilogue', 'slab_reduce')    # the last two no longer exist since round 2
 path = sys.argv[1]
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else None
-spans, total, fwd_passes = [], 0, 0
+spans, allspans, total, fwd_passes = [], [], 0, 0
 with open(path) as fh:
     for row in csv.DictReader(fh):
         if 'nchw_to_nhwc_kernel' in row['Kernel_Name']:
             fwd_passes += 1
+        s, e = int(row['Start_Timestamp']), int(row['End_Timestamp'])
+        allspans.append((s, e))
         if any(f in row['Kernel_Name'] for f in FAMILY):
-            s, e = int(row['Start_Timestamp']), int(row['End_Timestamp'])
             spans.append((s, e))
             total += e - s
-spans.sort()
-busy, cs, ce = 0, None, None
-for s, e in spans:
-    if ce is None or s > ce:
-        if ce is not None:
-            busy += ce - cs
-        cs, ce = s, e
-    else:
-        ce = max(ce, e)
-if ce is not None:
-    busy += ce - cs
+
+
+def union(sp):
+    sp = sorted(sp)
+    busy, cs, ce = 0, None, None
+    for s, e in sp:
+        if ce is None or s > ce:
+            if ce is not None:
+                busy += ce - cs
+            cs, ce = s, e
+        else:
+            ce = max(ce, e)
+    if ce is not None:
+        busy += ce - cs
+    return busy
+
+
+busy = union(spans)
+busy_all = union(allspans)      # any kernel running: step time minus this is the GPU sitting idle between launches
 if steps is None:
     steps = float(max(fwd_passes, 1))
 print(json.dumps({'conv_family_kernels': len(spans), 'steps': steps, 'busy_union_ms_per_step': busy / steps * 1e-6,
-                  'summed_durations_ms_per_step': total / steps * 1e-6}))
+                  'summed_durations_ms_per_step': total / steps * 1e-6, 'all_kernels_busy_union_ms_per_step': busy_all / steps * 1e-6}))
