@@ -269,31 +269,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
 // invariant; padding / tile-edge lanes are pointed past the descriptor's range and read zeros from the
 // hardware bounds check instead of branching.
 // ---------------------------------------------------------------------------
-// x / d for 0 <= x < 2^31 without a divide: the compiler's sequence for a run-time divisor is ~30 dependent instructions
-// (float reciprocal + two correction steps), and the index decode of a workgroup needs five of them before its first load.
-//   d == 1: mul == 0 (identity);  d == 2^k: shift = k - 1, mul = 2^31 + 1;  else shift = floor(log2 d), mul = floor(2^(32+shift) / d) + 1
-// (error term mul * d - 2^(32+shift) <= d, so floor is exact while x * d < 2^(32+shift), i.e. for every x < 2^31).
-struct Y3Div {
-    unsigned mul;
-    int shift;
-};
-static Y3Div y3_make_div(int d) {
-    Y3Div r = {0u, 0};
-    if (d <= 1) return r;
-    int s = 0;
-    while ((2LL << s) <= d) ++s;      // floor(log2 d)
-    if ((1LL << s) == d) {
-        r.shift = s - 1;
-        r.mul = 0x80000001u;
-    } else {
-        r.shift = s;
-        r.mul = (unsigned)(((1ULL << (32 + s)) / (unsigned long long)d) + 1ULL);
-    }
-    return r;
-}
-__device__ __forceinline__ int y3_div(int x, const Y3Div d) { return d.mul ? (int)(__umulhi((unsigned)x, d.mul) >> d.shift) : x; }
-#define Y3_PIN_S(x) asm volatile("" : "+s"(x))
-
 struct FastArgs {
     const float* src;  // biased so that every tap offset is >= 0
     const float* wt;

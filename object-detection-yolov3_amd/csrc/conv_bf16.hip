@@ -37,6 +37,8 @@ struct Bf16Args {
     unsigned flags;
     float alpha;
     int nbn, out_f32, vec_ok;
+    int ohw;
+    Y3Div dv_nbn, dv_ohw, dv_ow;   // index decode without run-time divides (y3_make_div)
 };
 
 #define Y3_OOB 0x80000000u
@@ -107,10 +109,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
+    // the scalars of the index decode, fetched from the argument segment in one batch (see conv_fast_body in conv.hip)
+    int nbn = p.nbn, ohw = p.ohw, OW = p.OW, aM = p.M, aH = p.H, aW = p.W, src_ld = p.src_ld, csh = p.sh, csw = p.sw, ntaps = p.ntaps;
+    unsigned dn_m = p.dv_nbn.mul, dohw_m = p.dv_ohw.mul, dow_m = p.dv_ow.mul;
+    int dn_s = p.dv_nbn.shift, dohw_s = p.dv_ohw.shift, dow_s = p.dv_ow.shift;
+    Y3_PIN_S(nbn); Y3_PIN_S(ohw); Y3_PIN_S(OW); Y3_PIN_S(aM); Y3_PIN_S(aH); Y3_PIN_S(aW); Y3_PIN_S(src_ld); Y3_PIN_S(csh); Y3_PIN_S(csw); Y3_PIN_S(ntaps);
+    Y3_PIN_S(dn_m); Y3_PIN_S(dohw_m); Y3_PIN_S(dow_m); Y3_PIN_S(dn_s); Y3_PIN_S(dohw_s); Y3_PIN_S(dow_s);
+    const Y3Div dv_nbn = {dn_m, dn_s}, dv_ohw = {dohw_m, dohw_s}, dv_ow = {dow_m, dow_s};
     const int bid = y3_xcd_remap(blockIdx.x, gridDim.x);
-    const int bm = bid / p.nbn, bn = bid % p.nbn;
+    const int bm = y3_div(bid, dv_nbn), bn = bid - bm * nbn;
     const int m0 = bm * BM, n0 = bn * BN;
-    const int ohw = p.OH * p.OW;
 
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.src), 0, p.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.wt), 0, p.wt_bytes, 0x00020000);
@@ -121,22 +129,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args 
     for (int i = 0; i < A_LOADS; ++i) {
         const int row = (tid + i * THREADS) / Q;
         const int m = m0 + row;
-        const bool ok = m < p.M;
+        const bool ok = m < aM;
         const int mm = ok ? m : 0;
-        const int n = mm / ohw;
+        const int n = y3_div(mm, dv_ohw);
         const int r = mm - n * ohw;
-        const int oh = r / p.OW;
-        const int ow = r - oh * p.OW;
-        const int ih0 = oh * p.sh, iw0 = ow * p.sw;
+        const int oh = y3_div(r, dv_ow);
+        const int ow = r - oh * OW;
+        const int ih0 = oh * csh, iw0 = ow * csw;
         // LDS-DMA writes lane l of a wave to (wave-uniform base) + 16 * l: the LDS image is lane-linear, so the XOR swizzle of
         // the 16-byte quads is applied to the SOURCE address: the lane that fills slot `quad` of row `row` fetches quad
         // quad ^ f(row)
         const int qsrc = quad ^ ((row >> SWZ_SHIFT) & SWZ_MASK);
-        a_voff[i] = (unsigned)(((n * p.H + ih0) * p.W + iw0) * p.src_ld + qsrc * 8) * 2u;
+        a_voff[i] = (unsigned)(((n * aH + ih0) * aW + iw0) * src_ld + qsrc * 8) * 2u;
         unsigned msk = 0;
-        for (int t = 0; t < p.ntaps; ++t) {
+        for (int t = 0; t < ntaps; ++t) {
             const int ih = ih0 + p.tap_dh[t], iw = iw0 + p.tap_dw[t];
-            if (ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) msk |= 1u << t;
+            if (ok && (unsigned)ih < (unsigned)aH && (unsigned)iw < (unsigned)aW) msk |= 1u << t;
         }
         a_mask[i] = msk;
     }
@@ -482,7 +490,12 @@ static int check_bf16_tensor(const y3_tensor* t, const char* name) {
 }
 
 template <int BM, int BN, int WM, int WN, bool STAGED = true, int BK = 32>
-static void launch_bf16(const Bf16Args& p, int grid, hipStream_t st) {
+static void launch_bf16(const Bf16Args& args, int grid, hipStream_t st) {
+    Bf16Args p = args;
+    p.ohw = p.OH * p.OW;
+    p.dv_nbn = y3_make_div(p.nbn);
+    p.dv_ohw = y3_make_div(p.ohw);
+    p.dv_ow = y3_make_div(p.OW);
     static const int nbuf = getenv("Y3_BF16_NBUF") ? atoi(getenv("Y3_BF16_NBUF")) : 3;     // ring depth (experiments): 2, 3 or 4
     if constexpr (BK == 32 && BM * BN <= 128 * 128) {
         if (nbuf == 4) {
