@@ -85,6 +85,17 @@ int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksize, int str
                     const y3_tensor* dsrc, unsigned flags, void* workspace, size_t workspace_bytes,
                     y3_stream_t stream);
 size_t y3_conv2d_dgrad_workspace(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc);
+/*
+ * y3_conv2d_dgrad whose epilogue also sums the six raw moments of (dsrc after this launch, bn_a) per output column and
+ * row tile -- the statistics of the BatchNorm backward of the layer that PRODUCED dsrc's activation (bn_a = that layer's
+ * lrelu(z), geometry of dsrc).  Use it for the launch that completes dsrc (the last accumulation).  Stride 1 and fast-path
+ * channel counts only: y3_conv2d_dgrad_bn_tiles() returns the number of row tiles (partials: tiles * 6 * dsrc->c floats,
+ * 16-byte aligned), or 0 when the shape does not qualify.  Same workspace as y3_conv2d_dgrad.
+ */
+int y3_conv2d_dgrad_bn(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc,
+                       unsigned flags, const y3_tensor* bn_a, float* bn_partials,
+                       void* workspace, size_t workspace_bytes, y3_stream_t stream);
+int y3_conv2d_dgrad_bn_tiles(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc);
 
 /*
  * Gradient w.r.t. the kernel:  dw[tap][ci][co] = sum_pixels src*ddst.
@@ -144,6 +155,17 @@ int y3_bn_bwd_stats(const y3_tensor* dy, const y3_tensor* a, const y3_tensor* dr
 size_t y3_bn_bwd_workspace(int m, int c); /* 0 if the channel count is unsupported */
 int y3_bn_bwd_apply(const y3_tensor* dy, const y3_tensor* a, const float* coef, float alpha,
                     const y3_tensor* dz, y3_stream_t stream);
+/* step 2 with the residual fan-in of model.py:47 riding along: dres = dy (dres_accumulate == 0) or dres += dy */
+int y3_bn_bwd_apply_fanin(const y3_tensor* dy, const y3_tensor* a, const float* coef, float alpha,
+                          const y3_tensor* dz, const y3_tensor* dres, int dres_accumulate, y3_stream_t stream);
+/*
+ * Step 1 without a pass of its own: when the LAST contribution to dy is written by a stride-1 data gradient
+ * (y3_conv2d_dgrad_bn above: its epilogue has dy in registers), that launch leaves per-row-tile partial moments
+ * [tiles][6][c] (fp32) and this call turns them into dgamma / dbeta / dbias / coef (fp64 across tiles).
+ */
+int y3_bn_bwd_finalize_tiles(const float* partials, int tiles, int c, int count, const float* gamma,
+                             const float* save_mean, const float* save_rstd, float alpha,
+                             float* dgamma, float* dbeta, float* dbias, float* coef, y3_stream_t stream);
 
 /* ---- upsample_2x: frozen all-ones Conv2DTranspose k2 s2 (model.py:94-105) ---- */
 /* out[n,2i+a,2j+b,co] = sum_ci in[n,i,j,ci] for every co */

@@ -44,6 +44,9 @@ struct ConvArgs {
     float alpha;
     int nbn;
     int src_n, wt_rows;  // host-side only: batch of src, rows of the weight matrix (descriptor sizes)
+    const float* bn_a;   // data gradient with BatchNorm-backward statistics in the epilogue (y3_conv2d_dgrad_bn): the activation `a`
+    float* bn_part;      // ... and the partial sums [row tile][6][Nout]
+    int bn_a_ld;
 };
 
 template <int BM, int BN, int WM, int WN, int BK>
@@ -308,6 +311,10 @@ struct FastArgs {
     float* slab;
     int* tickets;        // one per tile, zero before the launch
     int stagger;         // units of 256 cycles by which co-resident workgroups are pushed out of phase before the K loop
+    const float* bn_a;   // BNS kernels: activation of the BatchNorm layer whose output gradient this launch completes (dst geometry)
+    float* bn_part;      // BNS kernels: [row tile][6][Nout] partial raw moments of (dst, bn_a), see bn_bwd_stats_kernel
+    unsigned bn_a_bytes;
+    int bn_a_ld;
 };
 
 #define Y3_OOB 0x80000000u
@@ -345,7 +352,7 @@ __device__ __forceinline__ void y3_sgb_pairs() {   // COUNT x { MFMAS matrix ins
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool DENSE, int PIPE = 0>
+template <int BM, int BN, int WM, int WN, int BK, bool DENSE, int PIPE = 0, bool BNS = false>
 __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw, const int grid) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int LDA = BK + 4;
@@ -358,7 +365,12 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
 
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
-    __shared__ float red[2][WM][BN];
+    // column sums of the epilogue (forward statistics: 2, BNS: 6 per column and wave row).  BNS: they live in the A stage, dead
+    // once the K loop is over -- at 64x64 the workgroup's LDS decides whether 8 or 7 workgroups share a CU, and the split-K plan
+    // (~2 000 workgroups) is sized for 8
+    static_assert(!BNS || 6 * WM * BN <= 2 * BM * LDA, "BNS column sums do not fit the A stage");
+    __shared__ float red_own[BNS ? 1 : 2][BNS ? 1 : WM][BNS ? 1 : BN];
+    float (*red)[WM][BN] = BNS ? reinterpret_cast<float (*)[WM][BN]>(&As[0][0]) : reinterpret_cast<float (*)[WM][BN]>(&red_own[0][0][0]);
 
     Y3_TSTAMP(0);
 #ifdef Y3_TIMING
@@ -772,6 +784,12 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
     float ssum[NB], ssq[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) ssum[j] = ssq[j] = 0.f;
+    float bsum[BNS ? 6 : 1][NB];
+#pragma unroll
+    for (int q = 0; q < (BNS ? 6 : 1); ++q)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) bsum[q][j] = 0.f;
+    static_assert(!BNS || DENSE, "BatchNorm-backward statistics are only built for the dense epilogue");
     if constexpr (DENSE) {
         // dense destination (pixel index == m): buffer stores with the row part of the offset in the scalar operand and
         // tile-edge lanes pointed out of range -- no per-element 64-bit address math, no divergent branches.  All 676
@@ -783,6 +801,11 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
         const unsigned ld4 = (unsigned)p.dst_ld * 4u, rld4 = (unsigned)p.resid_ld * 4u;
         const bool full = m0 + BM <= p.M;  // wave-uniform: only the last row tile needs per-row masking
         const bool has_scale = p.scale != nullptr, has_resid = p.resid != nullptr;
+        // BNS: this launch completes the output gradient dy of a BatchNorm layer, so the six raw moments of (dy, a) that its
+        // backward needs (pointwise.hip, bn_bwd_stats_kernel) are summed here, while dy is in registers -- the separate pass
+        // over dy and a is gone.  `a` has the geometry of dst; lanes outside the tile read zeros (no contribution).
+        const __amdgpu_buffer_rsrc_t rs_bna = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNS ? p.bn_a : p.dst), 0, BNS ? p.bn_a_bytes : 0u, 0x00020000);
+        const unsigned ald4 = (unsigned)p.bn_a_ld * 4u;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int n = n0 + wn * TN + j * 32 + l31;
@@ -792,6 +815,7 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
             const float sf = (has_scale && nok) ? p.shift[n] : 0.f;
             const unsigned vbase = nok ? (unsigned)mrow * ld4 + (unsigned)n * 4u : Y3_OOB;
             const unsigned rbase = nok ? (unsigned)mrow * rld4 + (unsigned)n * 4u : Y3_OOB;
+            const unsigned abase = nok ? (unsigned)mrow * ald4 + (unsigned)n * 4u : Y3_OOB;
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
 #pragma unroll
@@ -802,11 +826,24 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
                     float v = acc[i][j][r] + bias;
                     if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
                     const float vs = ok ? v : 0.f;
-                    ssum[j] += vs;
-                    ssq[j] += vs * vs;
+                    if constexpr (!BNS) {
+                        ssum[j] += vs;
+                        ssq[j] += vs * vs;
+                    }
                     if (has_scale) v = v * sc + sf;
                     if (has_resid) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, ok ? rbase : Y3_OOB, (unsigned)dr * rld4, 0));
                     if (do_accum) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_dst, vo, (unsigned)dr * ld4, 0));
+                    if constexpr (BNS) {
+                        const float av = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_bna, ok ? abase : Y3_OOB, (unsigned)dr * ald4, 0));
+                        const float dv = ok ? v : 0.f;
+                        const bool pos = av > 0.f;
+                        bsum[0][j] += dv;
+                        bsum[1][j] += dv * av;
+                        bsum[2][j] += pos ? dv : 0.f;
+                        bsum[3][j] += pos ? av : 0.f;
+                        bsum[4][j] += pos ? 1.f : 0.f;
+                        bsum[5][j] += av;
+                    }
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_dst, vo, (unsigned)dr * ld4, 0);
                 }
             }
@@ -859,7 +896,26 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
             }
         }
     }
-    if (p.stats) {
+    if constexpr (BNS) {
+        // fixed order: lane halves, then the WM waves of a column -- deterministic, no atomics (as the forward statistics below)
+        __syncthreads();      // `red` aliases the A stage: every wave must be done with its last fragment reads
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float s = bsum[q][j] + __shfl_xor(bsum[q][j], 32);
+                if (lh == 0) red[q][wm][wn * TN + j * 32 + l31] = s;
+            }
+        __syncthreads();
+        for (int c = tid; c < 6 * BN; c += THREADS) {
+            const int which = c / BN, col = c % BN;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) s += red[which][w][col];
+            const int n = n0 + col;
+            if (n < p.Nout) p.bn_part[((long long)bm * 6 + which) * p.Nout + n] = s;
+        }
+    } else if (p.stats) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const float s = ssum[j] + __shfl_xor(ssum[j], 32);
@@ -886,9 +942,10 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
     Y3_TSTAMP(3);
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool DENSE, int PIPE>
-__global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_kernel(const FastArgs p) {
-    conv_fast_body<BM, BN, WM, WN, BK, DENSE, PIPE>(p, (int)blockIdx.x, (int)gridDim.x);
+// registers: at least 3 waves per SIMD; the BNS 64x64 variant must also stay at 64 VGPRs (8 waves per SIMD like its plain twin, see `red`)
+template <int BM, int BN, int WM, int WN, int BK, bool DENSE, int PIPE, bool BNS = false>
+__global__ __launch_bounds__(64 * WM * WN, (BNS && BM * BN <= 64 * 64) ? 8 : 3) void conv_igemm_fast_kernel(const FastArgs p) {
+    conv_fast_body<BM, BN, WM, WN, BK, DENSE, PIPE, BNS>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Up to four independent gather-GEMMs in ONE launch: the (row parity, column parity) classes of a stride-2 data gradient.
@@ -1458,6 +1515,12 @@ template <int BM, int BN, int WM, int WN, int BK>
 static void launch_fast(const FastArgs& p, bool dense, int grid, hipStream_t st) {
     static const int pipe = env_int("Y3_PIPE", 2);
     const dim3 g(grid), b(64 * WM * WN);
+    if constexpr (BK == 16) {
+        if (p.bn_a) {      // launch_igemm has checked: dense destination
+            hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, true, 2, true>), g, b, 0, st, p);
+            return;
+        }
+    }
     if (pipe == 2) {
         if (dense)
             hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, true, 2>), g, b, 0, st, p);
@@ -1543,6 +1606,10 @@ static bool make_fast(const ConvArgs& a, int ntaps, int bk, FastArgs* f) {
     p.shift = a.shift;
     p.resid = a.resid;
     p.stats = a.stats;
+    p.bn_a = a.bn_a;
+    p.bn_part = a.bn_part;
+    p.bn_a_ld = a.bn_a_ld;
+    p.bn_a_bytes = a.bn_a ? (unsigned)((long long)a.M * a.bn_a_ld * 4) : 0u;
     p.H = a.H;
     p.W = a.W;
     p.logC = a.logC;
@@ -1607,6 +1674,10 @@ static int launch_igemm(const ConvArgs& a, void* workspace, size_t workspace_byt
         f.slab = pl.ws_bytes ? (float*)((char*)workspace + Y3_WS_HEADER) : nullptr;
         const int grid = f.sk_n0 + (tiles - pl.f) * pl.s1;
         const bool dense = p.dense_dst != 0;
+        if (p.bn_a && (!dense || t.bk != 16)) {
+            y3_set_error("conv: BatchNorm-backward statistics need the dense fast kernel with K steps of 16");
+            return Y3_EINVAL;
+        }
         switch (key) {
             case 128 * 10000 + 128 * 10 + 0: launch_fast<128, 128, 2, 2, 16>(f, dense, grid, st); break;
             case 128 * 10000 + 128 * 10 + 1: launch_fast<128, 128, 2, 2, 32>(f, dense, grid, st); break;
@@ -1624,6 +1695,10 @@ static int launch_igemm(const ConvArgs& a, void* workspace, size_t workspace_byt
         }
         Y3_CHECK_LAUNCH("conv_igemm_fast");
         return Y3_OK;
+    }
+    if (p.bn_a) {
+        y3_set_error("conv: BatchNorm-backward statistics are not available on the generic kernel (shape %d x %d x %d)", p.M, p.Nout, p.K);
+        return Y3_EINVAL;
     }
     const int grid = tiles;
     switch (key) {
@@ -1774,8 +1849,37 @@ static bool launch_dgrad_multi(const ConvArgs* cls, int ncls, hipStream_t st) {
     return true;
 }
 
+static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc, unsigned flags,
+                             const y3_tensor* bn_a, float* bn_partials, void* workspace, size_t workspace_bytes, y3_stream_t stream);
+
 extern "C" int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc, unsigned flags,
                                void* workspace, size_t workspace_bytes, y3_stream_t stream) {
+    return conv2d_dgrad_impl(ddst, wt_t, ksize, stride, dsrc, flags, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+// Row tiles of the partial statistics y3_conv2d_dgrad_bn writes for this shape, 0 if the shape does not qualify (stride 2,
+// channel counts off the fast path): the caller then runs y3_bn_bwd_stats on the finished gradient instead.
+extern "C" int y3_conv2d_dgrad_bn_tiles(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc) {
+    if (!ddst || !dsrc || stride != 1 || (ksize != 1 && ksize != 3)) return 0;
+    const int taps = ksize * ksize, K = taps * ddst->c, M = dsrc->n * dsrc->h * dsrc->w;
+    if (!fast_shape_ok(ddst->c, dsrc->c, K, taps)) return 0;
+    const ConvPlan pl = plan_conv(M, dsrc->c, K, true);
+    if (pl.t.bk != 16) return 0;
+    return y3_cdiv(M, pl.t.bm);
+}
+
+extern "C" int y3_conv2d_dgrad_bn(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc, unsigned flags,
+                                  const y3_tensor* bn_a, float* bn_partials, void* workspace, size_t workspace_bytes, y3_stream_t stream) {
+    if (int e = check_tensor(bn_a, "conv2d_dgrad_bn bn_a")) return e;
+    Y3_CHECK_ARG(bn_partials, "conv2d_dgrad_bn: null partials");
+    Y3_CHECK_ARG(dsrc && bn_a->n == dsrc->n && bn_a->h == dsrc->h && bn_a->w == dsrc->w && bn_a->c == dsrc->c, "conv2d_dgrad_bn: bn_a must have dsrc's geometry");
+    Y3_CHECK_ARG((long long)bn_a->n * bn_a->h * bn_a->w * bn_a->ld * 4 < 0x7fffffffLL, "conv2d_dgrad_bn: bn_a of 2 GiB or more");
+    Y3_CHECK_ARG(y3_conv2d_dgrad_bn_tiles(ddst, ksize, stride, dsrc) > 0, "conv2d_dgrad_bn: shape does not qualify (y3_conv2d_dgrad_bn_tiles() == 0)");
+    return conv2d_dgrad_impl(ddst, wt_t, ksize, stride, dsrc, flags, bn_a, bn_partials, workspace, workspace_bytes, stream);
+}
+
+static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc, unsigned flags,
+                             const y3_tensor* bn_a, float* bn_partials, void* workspace, size_t workspace_bytes, y3_stream_t stream) {
     if (int e = check_tensor(ddst, "conv2d_dgrad ddst")) return e;
     if (int e = check_tensor(dsrc, "conv2d_dgrad dsrc")) return e;
     Y3_CHECK_ARG(wt_t, "conv2d_dgrad: null weights");
@@ -1819,8 +1923,14 @@ extern "C" int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksi
         p.dense_dst = 1;
         p.K = taps * ddst->c;
         p.M = dsrc->n * p.OH * p.OW;
+        if (bn_a) {
+            p.bn_a = bn_a->ptr;
+            p.bn_a_ld = bn_a->ld;
+            p.bn_part = bn_partials;
+        }
         return launch_igemm(p, workspace, workspace_bytes, (hipStream_t)stream);
     }
+    Y3_CHECK_ARG(!bn_a, "conv2d_dgrad_bn: stride 2 is not supported");
     // stride 2: forward out o reads in[2o + k - pad]; input pixel i = 2q + par receives from the taps with
     // (par + pad - k) even, at o = q + (par + pad - k)/2.  One launch per (row parity, col parity).
     ConvArgs cls[4];

@@ -455,8 +455,70 @@ extern "C" int y3_bn_bwd_stats(const y3_tensor* dy, const y3_tensor* a, const y3
     return Y3_OK;
 }
 
+// The same coefficients from the [row tile][6][C] fp32 partial moments that y3_conv2d_dgrad_bn leaves behind (conv.hip, BNS
+// epilogue: sums over the <= 128 rows of a tile in fp32, tiles added here in fp64).  A block owns 4 channels: 128 tile lanes x
+// 6 sums = 768 threads, one float4 per tile row; C/4 blocks.
+__global__ __launch_bounds__(768) void bn_bwd_finalize_tiles_kernel(const float* __restrict__ partials, int tiles, int C, double count, float alpha,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd, float* dgamma, float* dbeta, float* dbias,
+                                                                    float* coef) {
+    __shared__ double sm[Y3_BNB_SUMS][128][4];
+    const int j = threadIdx.x % Y3_BNB_SUMS, lane = threadIdx.x / Y3_BNB_SUMS;
+    const int c0 = blockIdx.x * 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t = lane; t < tiles; t += 128) {
+        const float4 v = *reinterpret_cast<const float4*>(partials + ((long long)t * Y3_BNB_SUMS + j) * C + c0);
+        acc[0] += (double)v.x;
+        acc[1] += (double)v.y;
+        acc[2] += (double)v.z;
+        acc[3] += (double)v.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm[j][lane][e] = acc[e];
+    __syncthreads();
+    for (int half = 64; half >= 1; half >>= 1) {
+        if (lane < half)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sm[j][lane][e] += sm[j][lane + half][e];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) {
+        const int e = threadIdx.x, c = c0 + e;
+        const double s0 = sm[0][0][e], s1 = sm[1][0][e], s2 = sm[2][0][e], s3 = sm[3][0][e], s4 = sm[4][0][e], s5 = sm[5][0][e];
+        const double ga = gamma[c], r = rstd[c], mu = mean[c], al = (double)alpha, inv_count = 1.0 / count;
+        const double db = s0;                                                    // sum dy
+        const double dg = r * (s1 - mu * s0);                                    // sum dy * xhat
+        const double sdys = al * s0 + (1.0 - al) * s2;                           // sum dy * slope
+        const double ss = al * count + (1.0 - al) * s4;                          // sum slope
+        const double sxs = r * ((1.0 - al) * (s3 - mu * s4) + al * (s5 - mu * count));   // sum xhat * slope
+        dgamma[c] = (float)dg;
+        dbeta[c] = (float)db;
+        dbias[c] = (float)(ga * r * (sdys - db * inv_count * ss - dg * inv_count * sxs));
+        const double k1 = ga * r;
+        const double k2 = -ga * r * r * dg * inv_count;
+        const double k3 = -ga * r * db * inv_count - k2 * mu;
+        coef[c] = (float)k1;
+        coef[C + c] = (float)k2;
+        coef[2 * C + c] = (float)k3;
+    }
+}
+extern "C" int y3_bn_bwd_finalize_tiles(const float* partials, int tiles, int c, int count, const float* gamma, const float* save_mean,
+                                        const float* save_rstd, float alpha, float* dgamma, float* dbeta, float* dbias, float* coef,
+                                        y3_stream_t stream) {
+    Y3_CHECK_ARG(partials && gamma && save_mean && save_rstd && dgamma && dbeta && dbias && coef, "bn_bwd_finalize_tiles: null pointer");
+    Y3_CHECK_ARG(tiles > 0 && c > 0 && count > 0, "bn_bwd_finalize_tiles: bad sizes");
+    Y3_CHECK_ARG((c & 3) == 0 && ((uintptr_t)partials & 15) == 0, "bn_bwd_finalize_tiles: channels must be a multiple of 4, partials 16-byte aligned");
+    hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel, dim3(c / 4), dim3(768), 0, (hipStream_t)stream, partials, tiles, c, (double)count, alpha, gamma,
+                       save_mean, save_rstd, dgamma, dbeta, dbias, coef);
+    Y3_CHECK_LAUNCH("bn_bwd_finalize_tiles");
+    return Y3_OK;
+}
+
+// dz = (k1*dy + k2*a + k3) * slope(a); RES: the residual fan-in dres (+)= dy rides along (dy is in registers)
+template <bool RES>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_ld, const float* __restrict__ a, int a_ld,
-                                    const float* __restrict__ coef, float alpha, float* __restrict__ dz, int dz_ld, long long npix, int C) {
+                                    const float* __restrict__ coef, float alpha, float* __restrict__ dz, int dz_ld, float* __restrict__ dres,
+                                    int dres_ld, int dres_acc, long long npix, int C) {
     const int c4n = C >> 2;
     const long long total = npix * c4n;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -468,6 +530,15 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_ld, con
         const float4 k1 = *reinterpret_cast<const float4*>(coef + c);
         const float4 k2 = *reinterpret_cast<const float4*>(coef + C + c);
         const float4 k3 = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+        if (RES) {
+            float4* q = reinterpret_cast<float4*>(dres + pix * dres_ld + c);
+            float4 o = d4;
+            if (dres_acc) {
+                const float4 t = *q;
+                o = make_float4(t.x + d4.x, t.y + d4.y, t.z + d4.z, t.w + d4.w);
+            }
+            *q = o;
+        }
         float4 o;
         o.x = (k1.x * d4.x + k2.x * a4.x + k3.x) * (a4.x > 0.f ? 1.f : alpha);
         o.y = (k1.y * d4.y + k2.y * a4.y + k3.y) * (a4.y > 0.f ? 1.f : alpha);
@@ -476,17 +547,33 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_ld, con
         *reinterpret_cast<float4*>(dz + pix * dz_ld + c) = o;
     }
 }
+static int bn_bwd_apply_launch(const char* what, const y3_tensor* dy, const y3_tensor* a, const float* coef, float alpha, const y3_tensor* dz,
+                               const y3_tensor* dres, int dres_accumulate, y3_stream_t stream) {
+    if (int e = check_view4(dy, what)) return e;
+    if (int e = check_view4(a, what)) return e;
+    if (int e = check_view4(dz, what)) return e;
+    Y3_CHECK_ARG(same_geom(dy, a) && same_geom(dy, dz) && coef, "%s: geometry/pointers", what);
+    const long long total = pixels(a) * (a->c / 4);
+    if (dres) {
+        if (int e = check_view4(dres, what)) return e;
+        Y3_CHECK_ARG(same_geom(dy, dres), "%s: dres geometry", what);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(stream_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, dy->ptr, dy->ld, a->ptr,
+                           a->ld, coef, alpha, dz->ptr, dz->ld, dres->ptr, dres->ld, dres_accumulate, pixels(a), a->c);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(stream_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, dy->ptr, dy->ld, a->ptr,
+                           a->ld, coef, alpha, dz->ptr, dz->ld, nullptr, 0, 0, pixels(a), a->c);
+    }
+    Y3_CHECK_LAUNCH(what);
+    return Y3_OK;
+}
 extern "C" int y3_bn_bwd_apply(const y3_tensor* dy, const y3_tensor* a, const float* coef, float alpha, const y3_tensor* dz,
                                y3_stream_t stream) {
-    if (int e = check_view4(dy, "bn_bwd_apply dy")) return e;
-    if (int e = check_view4(a, "bn_bwd_apply a")) return e;
-    if (int e = check_view4(dz, "bn_bwd_apply dz")) return e;
-    Y3_CHECK_ARG(same_geom(dy, a) && same_geom(dy, dz) && coef, "bn_bwd_apply: geometry/pointers");
-    const long long total = pixels(a) * (a->c / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, dy->ptr, dy->ld, a->ptr,
-                       a->ld, coef, alpha, dz->ptr, dz->ld, pixels(a), a->c);
-    Y3_CHECK_LAUNCH("bn_bwd_apply");
-    return Y3_OK;
+    return bn_bwd_apply_launch("bn_bwd_apply", dy, a, coef, alpha, dz, nullptr, 0, stream);
+}
+extern "C" int y3_bn_bwd_apply_fanin(const y3_tensor* dy, const y3_tensor* a, const float* coef, float alpha, const y3_tensor* dz,
+                                     const y3_tensor* dres, int dres_accumulate, y3_stream_t stream) {
+    Y3_CHECK_ARG(dres && dres->ptr, "bn_bwd_apply_fanin: null dres");
+    return bn_bwd_apply_launch("bn_bwd_apply_fanin", dy, a, coef, alpha, dz, dres, dres_accumulate, stream);
 }
 
 // ---------------------------------------------------------------------------

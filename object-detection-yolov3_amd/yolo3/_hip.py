@@ -45,6 +45,8 @@ SIGNATURES = {
     'y3_conv2d_fwd_workspace': (sz, [i32, i32, i32, i32]),
     'y3_conv2d_dgrad': (i32, [TP, fp, i32, i32, TP, u32, vp, sz, vp]),
     'y3_conv2d_dgrad_workspace': (sz, [TP, i32, i32, TP]),
+    'y3_conv2d_dgrad_bn': (i32, [TP, fp, i32, i32, TP, u32, TP, fp, vp, sz, vp]),
+    'y3_conv2d_dgrad_bn_tiles': (i32, [TP, i32, i32, TP]),
     'y3_conv2d_wgrad': (i32, [TP, TP, i32, i32, fp, vp, sz, vp]),
     'y3_conv2d_wgrad_workspace': (sz, [TP, TP, i32, i32]),
     'y3_transpose_weights': (i32, [fp, fp, i32, i32, i32, vp]),
@@ -56,6 +58,8 @@ SIGNATURES = {
     'y3_bn_bwd_stats': (i32, [TP, TP, TP, i32, fp, fp, fp, f32, fp, fp, fp, fp, vp, sz, vp]),
     'y3_bn_bwd_workspace': (sz, [i32, i32]),
     'y3_bn_bwd_apply': (i32, [TP, TP, fp, f32, TP, vp]),
+    'y3_bn_bwd_apply_fanin': (i32, [TP, TP, fp, f32, TP, TP, i32, vp]),
+    'y3_bn_bwd_finalize_tiles': (i32, [fp, i32, i32, i32, fp, fp, fp, f32, fp, fp, fp, fp, vp]),
     'y3_upsample_sum2x_fwd': (i32, [TP, TP, vp]),
     'y3_upsample_sum2x_bwd': (i32, [TP, TP, vp]),
     'y3_copy': (i32, [TP, TP, vp]),

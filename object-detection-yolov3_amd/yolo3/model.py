@@ -22,6 +22,7 @@ from ._hip import lib, check, view, EPI_LRELU, EPI_ACCUM
 
 BN_EPS = 1e-3          # Keras BatchNormalization defaults
 BN_MOMENTUM = 0.99
+BN_EPILOGUE_STATS = os.environ.get('Y3_BN_EPI', '1') != '0'   # BatchNorm-backward statistics from the epilogue of the data gradient that completes dy
 LRELU_ALPHA = 0.2      # tf.nn.leaky_relu default (App. C3)
 ALIGN = 64             # arena alignment in floats (256 B)
 
@@ -416,6 +417,46 @@ class _Plan:
         self.wg_ws = torch.zeros(max(wg_need // 4, 4), dtype=torch.float32, device=mdl.device)      # tickets + slabs, zeroed once
         self.wg_ws_bytes = wg_need
 
+        # BatchNorm-backward statistics without a pass of their own: the gradient dy of a layer's output is complete when the
+        # data gradient of its FIRST consumer in forward order has run (later consumers -- residual adds, routes -- are
+        # visited earlier by the reversed walk).  If that consumer is a stride-1 convolution reading exactly this tensor
+        # and the shape qualifies (y3_conv2d_dgrad_bn_tiles), its data gradient sums the raw moments in its epilogue and
+        # the producer only needs y3_bn_bwd_finalize_tiles; every other layer keeps y3_bn_bwd_stats.
+        epi_of = {}            # id(consumer op) -> (producer activation a, partial buffer, tiles)
+        epi_for = {}           # id(producer op) -> (partial buffer, tiles)
+        if BN_EPILOGUE_STATS:
+            first_consumer = {}
+            for op in self.ops:
+                reads = []
+                if op[0] == 'conv_layer':
+                    reads = [op[2]] + ([op[5]] if op[5] is not None else [])
+                elif op[0] == 'head':
+                    reads = [op[2]]
+                elif op[0] == 'upsample':
+                    reads = [op[1]]
+                for t in reads:
+                    first_consumer.setdefault(id(t), op)
+                    if t.parent is not None:
+                        first_consumer.setdefault(id(t.parent), op)
+                    for ch in t.children:
+                        first_consumer.setdefault(id(ch), op)
+            for op in self.ops:
+                if op[0] != 'conv_layer':
+                    continue
+                _, i, src, a, y, resid, _ = op
+                cons = first_consumer.get(id(y))
+                if cons is None or cons[0] != 'conv_layer' or cons[2] is not y or y.parent is not None or y.children or y is self.x0:
+                    continue
+                csp = specs[cons[1]]
+                ca = cons[3]
+                dd = view(self.dz, ca.n, ca.h, ca.w, csp.cout)
+                tiles = int(lib.y3_conv2d_dgrad_bn_tiles(dd, csp.k, csp.s, y.v))
+                if tiles <= 0:
+                    continue
+                part = torch.empty(tiles * 6 * y.c, dtype=torch.float32, device=mdl.device)
+                epi_of[id(cons)] = (a, part, tiles)
+                epi_for[id(op)] = (part, tiles)
+        self.epilogue_stats_layers = len(epi_for)
         first_src = self.x0
         # The kernel gradient of a layer and its data gradient both start from dz and are independent.  Each is a single
         # round of workgroups with ~8 us of prologue + epilogue in which the matrix pipe idles, so the kernel gradients go to
@@ -471,13 +512,25 @@ class _Plan:
                 nconv += 1
                 dz = _T(dz_bufs[slot], a.n, a.h, a.w, sp.cout)
                 self.keep.append(dz)
-                assert int(lib.y3_bn_bwd_workspace(a.m, sp.cout)) <= self.bnb_ws.numel()
-                self._emit(self.bwd, lib.y3_bn_bwd_stats, dy.v, a.v, dr.v if dr is not None else None, dr_acc if dr is not None else 0,
-                           mdl.params.data_ptr() + 4 * sp.g_off, smean, srstd, LRELU_ALPHA, gptr(sp.g_off), gptr(sp.be_off), gptr(sp.b_off), coef,
-                           self.bnb_ws.data_ptr(), self.bnb_ws.numel())
-                if two and dz_busy[slot] is not None:
-                    self.bwd.append(('main_wait', dz_busy[slot]))
-                self._emit(self.bwd, lib.y3_bn_bwd_apply, dy.v, a.v, coef, LRELU_ALPHA, dz.v)
+                if id(op) in epi_for:
+                    # the statistics were summed by the data gradient that completed dy: finalize, then apply (+ residual fan-in)
+                    part, tiles = epi_for[id(op)]
+                    self._emit(self.bwd, lib.y3_bn_bwd_finalize_tiles, part.data_ptr(), tiles, sp.cout, a.m, mdl.params.data_ptr() + 4 * sp.g_off,
+                               smean, srstd, LRELU_ALPHA, gptr(sp.g_off), gptr(sp.be_off), gptr(sp.b_off), coef)
+                    if two and dz_busy[slot] is not None:
+                        self.bwd.append(('main_wait', dz_busy[slot]))
+                    if dr is not None:
+                        self._emit(self.bwd, lib.y3_bn_bwd_apply_fanin, dy.v, a.v, coef, LRELU_ALPHA, dz.v, dr.v, dr_acc)
+                    else:
+                        self._emit(self.bwd, lib.y3_bn_bwd_apply, dy.v, a.v, coef, LRELU_ALPHA, dz.v)
+                else:
+                    assert int(lib.y3_bn_bwd_workspace(a.m, sp.cout)) <= self.bnb_ws.numel()
+                    self._emit(self.bwd, lib.y3_bn_bwd_stats, dy.v, a.v, dr.v if dr is not None else None, dr_acc if dr is not None else 0,
+                               mdl.params.data_ptr() + 4 * sp.g_off, smean, srstd, LRELU_ALPHA, gptr(sp.g_off), gptr(sp.be_off), gptr(sp.b_off), coef,
+                               self.bnb_ws.data_ptr(), self.bnb_ws.numel())
+                    if two and dz_busy[slot] is not None:
+                        self.bwd.append(('main_wait', dz_busy[slot]))
+                    self._emit(self.bwd, lib.y3_bn_bwd_apply, dy.v, a.v, coef, LRELU_ALPHA, dz.v)
                 if two:
                     self.events += [torch.cuda.Event(), torch.cuda.Event()]
                     e_dz, e_wg = len(self.events) - 2, len(self.events) - 1
@@ -490,8 +543,15 @@ class _Plan:
                     self._emit(self.bwd, lib.y3_conv2d_wgrad, src.v, dz.v, sp.k, sp.s, gptr(sp.w_off), self.wg_ws.data_ptr(), self.wg_ws_bytes)
                 if src is not first_src:
                     ds = self._grad_of(src)
-                    self._conv_call(self.bwd, ds.m, sp, lib.y3_conv2d_dgrad, dz.v, Wt.data_ptr() + 4 * sp.w_off, sp.k, sp.s, ds.v,
-                                    EPI_ACCUM if src.gw else 0, need=int(lib.y3_conv2d_dgrad_workspace(dz.v, sp.k, sp.s, ds.v)))
+                    if id(op) in epi_of:      # this launch completes d(src): it also sums the BatchNorm-backward moments of the producer
+                        pa, part, _ = epi_of[id(op)]
+                        self._conv_call(self.bwd, ds.m, sp, lib.y3_conv2d_dgrad_bn, dz.v, Wt.data_ptr() + 4 * sp.w_off, sp.k, sp.s, ds.v,
+                                        EPI_ACCUM if src.gw else 0, pa.v, part.data_ptr(),
+                                        need=int(lib.y3_conv2d_dgrad_workspace(dz.v, sp.k, sp.s, ds.v)))
+                        self.keep.append(part)
+                    else:
+                        self._conv_call(self.bwd, ds.m, sp, lib.y3_conv2d_dgrad, dz.v, Wt.data_ptr() + 4 * sp.w_off, sp.k, sp.s, ds.v,
+                                        EPI_ACCUM if src.gw else 0, need=int(lib.y3_conv2d_dgrad_workspace(dz.v, sp.k, sp.s, ds.v)))
                     src.mark_written()
                 self.bwd.append(('layer_done', i))
         for e in dz_busy + head_wg[-1:]:

@@ -292,6 +292,75 @@ def test_conv_dgrad(hip, case, accum):
     assert_close(dsv.cpu(), ref, rtol=2e-5, what='dgrad')
 
 
+@pytest.mark.parametrize('shape', [(8, 13, 13, 512, 1024, 3), (8, 26, 26, 128, 256, 1), (2, 52, 52, 64, 128, 3), (8, 52, 52, 128, 256, 3), (1, 13, 15, 64, 32, 1)])
+@pytest.mark.parametrize('accum', [False, True])
+def test_conv_dgrad_bn_epilogue_stats(hip, shape, accum):
+    """y3_conv2d_dgrad_bn: the data gradient is bit-identical to y3_conv2d_dgrad's, and the per-row-tile partial moments
+    it leaves behind, through y3_bn_bwd_finalize_tiles, give the dgamma / dbeta / dbias / coefficients that y3_bn_bwd_stats
+    computes from the finished gradient (fp32 tile sums vs fp64 running sums: 2e-5 of the largest value per quantity;
+    dbias is a difference of such sums, compared at 1e-4 of sum|dz| like test_batchnorm_train_fwd_bwd)."""
+    from util import nhwc_buf, stream, assert_close
+    n, h, w, cin, cout, k = shape          # conv cin -> cout; its data gradient has cin channels
+    g = torch.Generator().manual_seed(cin * 3 + cout + k)
+    dy = torch.randn(n, h, w, cout, generator=g)
+    wk = torch.randn(k, k, cin, cout, generator=g) * 0.05
+    a = torch.randn(n, h, w, cin, generator=g)            # activation of the layer that produced the conv's input
+    a = torch.where(a > 0, a, 0.2 * a)
+    init = torch.randn(n, h, w, cin, generator=g)
+    _, ddv = nhwc_buf(n, h, w, cout)
+    ddv.copy_(dy)
+    _, av = nhwc_buf(n, h, w, cin, ld=cin + 8)
+    av.copy_(a)
+    wt = wk.permute(0, 1, 3, 2).contiguous().cuda()
+    DD, A = hip.Tensor(ddv.data_ptr(), n, h, w, cout, cout), hip.Tensor(av.data_ptr(), n, h, w, cin, cin + 8)
+    outs = []
+    for fused in (False, True):
+        _, dsv = nhwc_buf(n, h, w, cin, ld=cin + 4, fill=0.0)
+        if accum:
+            dsv.copy_(init)
+        DS = hip.Tensor(dsv.data_ptr(), n, h, w, cin, cin + 4)
+        wsb = int(hip.lib.y3_conv2d_dgrad_workspace(DD, k, 1, DS))
+        ws = torch.zeros(wsb // 4 + 4, device='cuda')
+        flags = hip.EPI_ACCUM if accum else 0
+        if fused:
+            tiles = int(hip.lib.y3_conv2d_dgrad_bn_tiles(DD, k, 1, DS))
+            assert tiles > 0
+            part = torch.full((tiles * 6 * cin,), float('nan'), device='cuda')
+            hip.check(hip.lib.y3_conv2d_dgrad_bn(DD, wt.data_ptr(), k, 1, DS, flags, A, part.data_ptr(), ws.data_ptr(), wsb, stream()))
+            assert not torch.isnan(part).any()
+        else:
+            hip.check(hip.lib.y3_conv2d_dgrad(DD, wt.data_ptr(), k, 1, DS, flags, ws.data_ptr(), wsb, stream()))
+        outs.append(dsv.clone().contiguous())
+    assert torch.equal(outs[0], outs[1]), 'dgrad_bn changed the data gradient'
+    M = n * h * w
+    gd, mean, rstd = torch.rand(cin, generator=g).cuda() + 0.5, torch.randn(cin, generator=g).cuda() * 0.1, torch.rand(cin, generator=g).cuda() + 0.5
+    ref = [torch.empty(cin, device='cuda') for _ in range(3)] + [torch.empty(3 * cin, device='cuda')]
+    got = [torch.empty(cin, device='cuda') for _ in range(3)] + [torch.empty(3 * cin, device='cuda')]
+    DSC = hip.Tensor(outs[0].data_ptr(), n, h, w, cin, cin)      # the finished gradient (contiguous copy)
+    bws_bytes = int(hip.lib.y3_bn_bwd_workspace(M, cin))
+    bws = torch.zeros(bws_bytes, device='cuda', dtype=torch.uint8)
+    hip.check(hip.lib.y3_bn_bwd_stats(DSC, A, None, 0, gd.data_ptr(), mean.data_ptr(), rstd.data_ptr(), 0.2, ref[0].data_ptr(), ref[1].data_ptr(),
+                                      ref[2].data_ptr(), ref[3].data_ptr(), bws.data_ptr(), bws_bytes, stream()))
+    hip.check(hip.lib.y3_bn_bwd_finalize_tiles(part.data_ptr(), tiles, cin, M, gd.data_ptr(), mean.data_ptr(), rstd.data_ptr(), 0.2,
+                                               got[0].data_ptr(), got[1].data_ptr(), got[2].data_ptr(), got[3].data_ptr(), stream()))
+    for name, r, x in zip(('dgamma', 'dbeta', 'dbias', 'coef'), ref, got):
+        if name == 'dbias':
+            # scale of the sums it is a difference of: sum |dz| <= sum |k1 dy| + ...
+            scale = float((ref[3][:cin].abs() * outs[0].abs().sum(dim=(0, 1, 2))).max())
+            assert_close(x.cpu(), r.cpu(), rtol=0, atol=1e-4 * scale, what=name)
+        else:
+            assert_close(x.cpu(), r.cpu(), rtol=2e-5, what=name)
+    # the apply kernel with the residual fan-in riding along
+    _, dzr = nhwc_buf(n, h, w, cin)
+    _, dzf = nhwc_buf(n, h, w, cin)
+    _, drv = nhwc_buf(n, h, w, cin, ld=cin + 12, fill=0.0)
+    DR = hip.Tensor(drv.data_ptr(), n, h, w, cin, cin + 12)
+    hip.check(hip.lib.y3_bn_bwd_apply(DSC, A, ref[3].data_ptr(), 0.2, hip.Tensor(dzr.data_ptr(), n, h, w, cin, cin), stream()))
+    for acc in (0, 1):
+        hip.check(hip.lib.y3_bn_bwd_apply_fanin(DSC, A, ref[3].data_ptr(), 0.2, hip.Tensor(dzf.data_ptr(), n, h, w, cin, cin), DR, acc, stream()))
+    assert torch.equal(dzr, dzf) and torch.equal(drv.cpu(), 2 * outs[0].cpu())
+
+
 WGRAD_CASES = CONV_CASES[:6] + CONV_CASES[9:10] + [(8, 52, 52, 128, 256, 1, 1), (2, 64, 64, 32, 64, 3, 2)]
 
 

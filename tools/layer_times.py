@@ -19,7 +19,7 @@ gts = [torch.from_numpy(x).cuda() for x in bench.synth_labels(np.random.default_
 yolo.train_step((images, gts))
 plan = yolo._plan(8, True)
 st = torch.cuda.current_stream().cuda_stream
-names = {'y3_conv2d_fwd': 'fwd', 'y3_conv2d_dgrad': 'dgrad', 'y3_conv2d_wgrad': 'wgrad'}
+names = {'y3_conv2d_fwd': 'fwd', 'y3_conv2d_dgrad': 'dgrad', 'y3_conv2d_dgrad_bn': 'dgradb', 'y3_conv2d_wgrad': 'wgrad'}
 best = {}
 for rep in range(3):
     recs = []
@@ -46,11 +46,11 @@ rows = []
 for i, (nm, args, a, b) in enumerate(recs):
     t = best[i]
     tot[nm] = tot.get(nm, 0) + t
-    if nm in ('fwd', 'dgrad', 'wgrad'):
+    if nm in ('fwd', 'dgrad', 'dgradb', 'wgrad'):
         if nm == 'fwd':
             src, dst, k, s = args[0], args[5], args[3], args[4]
             m, cin, cout = dst.n * dst.h * dst.w, src.c, dst.c
-        elif nm == 'dgrad':
+        elif nm in ('dgrad', 'dgradb'):
             dd, ds, k, s = args[0], args[4], args[2], args[3]
             m, cin, cout = dd.n * dd.h * dd.w, ds.c, dd.c
         else:
