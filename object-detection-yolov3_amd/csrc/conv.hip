@@ -806,6 +806,9 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
         // over dy and a is gone.  `a` has the geometry of dst; lanes outside the tile read zeros (no contribution).
         const __amdgpu_buffer_rsrc_t rs_bna = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNS ? p.bn_a : p.dst), 0, BNS ? p.bn_a_bytes : 0u, 0x00020000);
         const unsigned ald4 = (unsigned)p.bn_a_ld * 4u;
+        const bool one_extra = has_resid != do_accum;
+        const __amdgpu_buffer_rsrc_t rs_ext = has_resid ? rs_res : rs_dst;
+        const unsigned xld4 = has_resid ? rld4 : ld4;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int n = n0 + wn * TN + j * 32 + l31;
@@ -816,6 +819,43 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
             const unsigned vbase = nok ? (unsigned)mrow * ld4 + (unsigned)n * 4u : Y3_OOB;
             const unsigned rbase = nok ? (unsigned)mrow * rld4 + (unsigned)n * 4u : Y3_OOB;
             const unsigned abase = nok ? (unsigned)mrow * ald4 + (unsigned)n * 4u : Y3_OOB;
+            const unsigned xbase = has_resid ? rbase : vbase;
+            // Exactly one extra operand per element (the residual of an inference layer, or the gradient a data gradient adds
+            // to): its loads are issued eight at a time from the one descriptor in use, then consumed.  As single loads inside the
+            // arithmetic they were sixteen dependent memory round trips per 32x32 block.  (Eight, not sixteen, in flight: the 64x64
+            // kernel must stay within 64 VGPRs -- 8 workgroups per CU -- see `red`.)
+            if (!BNS && one_extra) {
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        float ext[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int r = g * 8 + q;
+                            const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+                            const bool ok = full ? nok : (nok && mrow + dr < p.M);
+                            ext[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_ext, ok ? xbase : Y3_OOB, (unsigned)dr * xld4, 0));
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int r = g * 8 + q;
+                            const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+                            const bool ok = full ? nok : (nok && mrow + dr < p.M);
+                            const unsigned vo = ok ? vbase : Y3_OOB;
+                            float v = acc[i][j][r] + bias;
+                            if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
+                            const float vs = ok ? v : 0.f;
+                            ssum[j] += vs;
+                            ssq[j] += vs * vs;
+                            if (has_scale) v = v * sc + sf;
+                            v += ext[q];
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_dst, vo, (unsigned)dr * ld4, 0);
+                        }
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
 #pragma unroll
