@@ -1027,7 +1027,10 @@ struct WgradArgs {
 #ifndef Y3_WGRAD_WAVES_EU
 #define Y3_WGRAD_WAVES_EU 3   // waves per SIMD the register allocation aims at (140 VGPRs; 2 lets the compiler take 204)
 #endif
-#define Y3_WG_TABLE 2048   // pixels per split the LDS pixel table holds (plan_wgrad keeps chunks below it)
+#ifndef Y3_WG_TABLE
+#define Y3_WG_TABLE 2048
+#endif
+//   // pixels per split the LDS pixel table holds (plan_wgrad keeps chunks below it)
 template <int BKR, int BN, int WM, int WN, int BP>
 __global__ __launch_bounds__(64 * WM * WN, Y3_WGRAD_WAVES_EU) void conv_wgrad_kernel(const WgradArgs p) {
     constexpr int THREADS = 64 * WM * WN;
