@@ -456,17 +456,21 @@ extern "C" int y3_bn_bwd_stats(const y3_tensor* dy, const y3_tensor* a, const y3
 }
 
 // The same coefficients from the [row tile][6][C] fp32 partial moments that y3_conv2d_dgrad_bn leaves behind (conv.hip, BNS
-// epilogue: sums over the <= 128 rows of a tile in fp32, tiles added here in fp64).  A block owns 4 channels: 128 tile lanes x
-// 6 sums = 768 threads, one float4 per tile row; C/4 blocks.
-__global__ __launch_bounds__(768) void bn_bwd_finalize_tiles_kernel(const float* __restrict__ partials, int tiles, int C, double count, float alpha,
+// epilogue: sums over the <= 128 rows of a tile in fp32, tiles added here in fp64).  A block owns 4 channels: 64 tile lanes x
+// 6 sums = 384 threads, one float4 per tile row; C/4 blocks.  LDS budget: this launch-bound kernel sits on the critical path
+// while the previous layer's kernel gradient fills the CUs from the second stream (3 workgroups x 48 KB of the 160 KB): with
+// 24 KB of LDS (128 lanes) its blocks waited for a kernel-gradient workgroup to retire -- 31.6 us per launch in the overlapped
+// step against 8.7 us alone; 12 KB fit beside them.
+#define Y3_BNF_LANES 64
+__global__ __launch_bounds__(Y3_BNF_LANES * Y3_BNB_SUMS) void bn_bwd_finalize_tiles_kernel(const float* __restrict__ partials, int tiles, int C, double count, float alpha,
                                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                     const float* __restrict__ rstd, float* dgamma, float* dbeta, float* dbias,
                                                                     float* coef) {
-    __shared__ double sm[Y3_BNB_SUMS][128][4];
+    __shared__ double sm[Y3_BNB_SUMS][Y3_BNF_LANES][4];
     const int j = threadIdx.x % Y3_BNB_SUMS, lane = threadIdx.x / Y3_BNB_SUMS;
     const int c0 = blockIdx.x * 4;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int t = lane; t < tiles; t += 128) {
+    for (int t = lane; t < tiles; t += Y3_BNF_LANES) {
         const float4 v = *reinterpret_cast<const float4*>(partials + ((long long)t * Y3_BNB_SUMS + j) * C + c0);
         acc[0] += (double)v.x;
         acc[1] += (double)v.y;
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(768) void bn_bwd_finalize_tiles_kernel(const float*
 #pragma unroll
     for (int e = 0; e < 4; ++e) sm[j][lane][e] = acc[e];
     __syncthreads();
-    for (int half = 64; half >= 1; half >>= 1) {
+    for (int half = Y3_BNF_LANES / 2; half >= 1; half >>= 1) {
         if (lane < half)
 #pragma unroll
             for (int e = 0; e < 4; ++e) sm[j][lane][e] += sm[j][lane + half][e];
@@ -508,7 +512,7 @@ extern "C" int y3_bn_bwd_finalize_tiles(const float* partials, int tiles, int c,
     Y3_CHECK_ARG(partials && gamma && save_mean && save_rstd && dgamma && dbeta && dbias && coef, "bn_bwd_finalize_tiles: null pointer");
     Y3_CHECK_ARG(tiles > 0 && c > 0 && count > 0, "bn_bwd_finalize_tiles: bad sizes");
     Y3_CHECK_ARG((c & 3) == 0 && ((uintptr_t)partials & 15) == 0, "bn_bwd_finalize_tiles: channels must be a multiple of 4, partials 16-byte aligned");
-    hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel, dim3(c / 4), dim3(768), 0, (hipStream_t)stream, partials, tiles, c, (double)count, alpha, gamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel, dim3(c / 4), dim3(Y3_BNF_LANES * Y3_BNB_SUMS), 0, (hipStream_t)stream, partials, tiles, c, (double)count, alpha, gamma,
                        save_mean, save_rstd, dgamma, dbeta, dbias, coef);
     Y3_CHECK_LAUNCH("bn_bwd_finalize_tiles");
     return Y3_OK;
