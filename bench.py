@@ -59,13 +59,15 @@ def tiled_4k(use_graph):
         with contextlib.redirect_stdout(io.StringIO()):
             inference_tiled.inference_image_tiled(mdl, big, [608, 608], 32, batch_size=25)
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            reps = 3
-            for _ in range(reps):
+            times = []
+            for _ in range(5):      # every image timed on its own: the path is host-driven (upload, launches on two streams, merge),
+                t1 = time.perf_counter()      # and one slow repetition on a shared box moved a 3-image mean from 30.4 to 38.8 ms
                 inference_tiled.inference_image_tiled(mdl, big, [608, 608], 32, batch_size=25)
-            torch.cuda.synchronize()
-        t = (time.perf_counter() - t1) / reps
-        out[prec] = {'ms_per_image_end_to_end': t * 1e3, 'tiles_per_s': 100 / t, 'conv_tflops_end_to_end': tile_fl * 100 / t / 1e12}
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t1)
+        t = sorted(times)[len(times) // 2]
+        out[prec] = {'ms_per_image_end_to_end': t * 1e3, 'statistic': 'median of 5 images', 'ms_min': min(times) * 1e3, 'ms_max': max(times) * 1e3,
+                     'tiles_per_s': 100 / t, 'conv_tflops_end_to_end': tile_fl * 100 / t / 1e12}
     del y
     torch.cuda.empty_cache()
     return out
