@@ -461,7 +461,9 @@ extern "C" int y3_bn_bwd_stats(const y3_tensor* dy, const y3_tensor* a, const y3
 // while the previous layer's kernel gradient fills the CUs from the second stream (3 workgroups x 48 KB of the 160 KB): with
 // 24 KB of LDS (128 lanes) its blocks waited for a kernel-gradient workgroup to retire -- 31.6 us per launch in the overlapped
 // step against 8.7 us alone; 12 KB fit beside them.
+#ifndef Y3_BNF_LANES
 #define Y3_BNF_LANES 64
+#endif
 __global__ __launch_bounds__(Y3_BNF_LANES * Y3_BNB_SUMS) void bn_bwd_finalize_tiles_kernel(const float* __restrict__ partials, int tiles, int C, double count, float alpha,
                                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                     const float* __restrict__ rstd, float* dgamma, float* dbeta, float* dbias,
@@ -470,6 +472,7 @@ __global__ __launch_bounds__(Y3_BNF_LANES * Y3_BNB_SUMS) void bn_bwd_finalize_ti
     const int j = threadIdx.x % Y3_BNB_SUMS, lane = threadIdx.x / Y3_BNB_SUMS;
     const int c0 = blockIdx.x * 4;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
     for (int t = lane; t < tiles; t += Y3_BNF_LANES) {
         const float4 v = *reinterpret_cast<const float4*>(partials + ((long long)t * Y3_BNB_SUMS + j) * C + c0);
         acc[0] += (double)v.x;
