@@ -77,7 +77,7 @@ constexpr int stage_rows(int bm, int tm, int cap) {
 }
 
 template <int BM, int BN, int WM, int WN, bool STAGED, int BK = 32, int NBUF = 3>
-__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const Bf16Args p) {
+__global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128) ? 3 : 1) void conv_bf16_kernel(const Bf16Args p) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int Q = BK / 8;             // 16-byte quads per row and K step (BK = 32: 64-byte rows, 64: 128-byte rows)
     constexpr int LDR = BK;               // row pitch in u16: no padding -- the 16-byte quads of a row are XOR-swizzled instead:
