@@ -2033,10 +2033,34 @@ static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize
 struct WgradPlan {
     int bkr, bn, splits, chunk, tiles;
 };
-static WgradPlan plan_wgrad(int K, int Nout, int M) {
+static WgradPlan plan_wgrad(int K, int Nout, int M, int taps) {
     WgradPlan w;
     w.bkr = (K <= 64) ? 64 : 128;
     w.bn = (Nout <= 32) ? 32 : (Nout <= 64 ? 64 : 128);
+    // Measured per shape (tools/conv_tune.py with Y3_WGRAD_TILE, batch 8 at 416^2): the 1x1 layers (8-11 K steps per split, slab
+    // traffic as large as the operands) run 20-25 % faster on 64x64 tiles; the 3x3 layers with large kernel matrices (26x26 and
+    // 13x13 grids: K*Nout >= 1M) 5-10 % faster on 128x64, the 104x104 layer (K = 576) 6 % faster on 64x128.
+    static const int shape_rules = env_int("Y3_WGRAD_SHAPE_RULES", 1);
+    if (shape_rules && w.bkr == 128 && w.bn == 128) {
+        if (taps == 1) {
+            w.bkr = 64;
+            w.bn = 64;
+        } else if ((long long)K * Nout >= (1 << 20)) {
+            w.bn = 64;
+        } else if (K <= 576) {
+            w.bkr = 64;
+        }
+    }
+    {
+        // experiments: Y3_WGRAD_TILE=bkr,bn (64|128, 32|64|128) for the layers with K <= Y3_WGRAD_TILE_MAXK (default 1024)
+        static const char* ov = getenv("Y3_WGRAD_TILE");
+        static const int maxk = env_int("Y3_WGRAD_TILE_MAXK", 1024);
+        int a = 0, b = 0;
+        if (ov && K <= maxk && sscanf(ov, "%d,%d", &a, &b) == 2 && (a == 64 || a == 128) && (b == 32 || b == 64 || b == 128) && b <= ((Nout + 31) / 32) * 32) {
+            w.bkr = a;
+            w.bn = b;
+        }
+    }
     w.tiles = y3_cdiv(K, w.bkr) * y3_cdiv(Nout, w.bn);
     // aim at ~16 waves per CU overall (these launches are latency / HBM bound per workgroup), at least 128 pixels per split
     static const int want_waves = env_int("Y3_WGRAD_WAVES", 4096);
@@ -2070,7 +2094,7 @@ extern "C" size_t y3_conv2d_wgrad_workspace(const y3_tensor* src, const y3_tenso
     (void)stride;
     const int K = ksize * ksize * src->c;
     const int M = ddst->n * ddst->h * ddst->w;
-    const WgradPlan w = plan_wgrad(K, ddst->c, M);
+    const WgradPlan w = plan_wgrad(K, ddst->c, M, ksize * ksize);
     return wgrad_ws_bytes(w, K, ddst->c);
 }
 
@@ -2112,7 +2136,7 @@ extern "C" int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int 
         p.src_bytes = (unsigned)sb;
         p.dd_bytes = (unsigned)db;
     }
-    const WgradPlan w = plan_wgrad(p.K, p.Nout, p.M);
+    const WgradPlan w = plan_wgrad(p.K, p.Nout, p.M, taps);
     p.chunk = w.chunk;
     p.nbn = y3_cdiv(p.Nout, w.bn);
     p.ohw = OH * OW;
