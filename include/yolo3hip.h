@@ -34,6 +34,9 @@ extern "C" {
 typedef void* y3_stream_t; /* hipStream_t */
 
 const char* y3_last_error(void);
+/* Diagnostics: x / d computed the way the kernels' index decode does it (multiply-high + shift, common.h y3_make_div),
+ * on the host; 0 <= x < 2^31, d >= 1.  The CPU tests compare it with the integer division it replaces. */
+int y3_debug_div(int x, int d);
 int y3_version(void);
 
 /* ---- epilogue flags of y3_conv2d_fwd / y3_conv2d_dgrad ------------------ */

@@ -11,4 +11,10 @@ void y3_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* y3_last_error(void) { return g_err; }
+
+// host twin of y3_div (common.h): same magic numbers, the multiply-high written out in 64 bits
+extern "C" int y3_debug_div(int x, int d) {
+    const Y3Div m = y3_make_div(d);
+    return m.mul ? (int)((unsigned)(((unsigned long long)(unsigned)x * m.mul) >> 32) >> m.shift) : x;
+}
 extern "C" int y3_version(void) { return 1; }

@@ -39,6 +39,7 @@ i32, u32, f32, sz = C.c_int, C.c_uint, C.c_float, C.c_size_t
 # name -> (restype, argtypes); every symbol declared in include/yolo3hip.h
 SIGNATURES = {
     'y3_last_error': (C.c_char_p, []),
+    'y3_debug_div': (i32, [i32, i32]),
     'y3_version': (i32, []),
     'y3_conv2d_fwd': (i32, [TP, fp, fp, i32, i32, TP, u32, f32, fp, fp, TP, fp, vp, sz, vp]),
     'y3_conv2d_stats_tiles': (i32, [i32, i32, i32, i32]),

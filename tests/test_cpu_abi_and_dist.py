@@ -49,6 +49,27 @@ def test_argument_validation_without_device():
     assert _hip.lib.y3_zscore_workspace_bytes(3) > 0 and _hip.lib.y3_loss_workspace_bytes() > 0
 
 
+def test_index_decode_division_is_exact():
+    """The kernels decode tile / pixel indices with multiply-high + shift instead of a divide (common.h y3_make_div / y3_div);
+    y3_debug_div is the host twin of the device function.  Every divisor the planners can produce (1 ... 4096, the OH*OW and
+    tile counts of the 416 / 608 configurations, powers of two, large primes) against x // d on edge values and random x."""
+    from yolo3 import _hip
+    rng = np.random.default_rng(5)
+    divisors = list(range(1, 4097)) + [13 * 13, 26 * 26, 52 * 52, 104 * 104, 208 * 208, 416 * 416, 19 * 19, 38 * 38, 76 * 76, 152 * 152,
+                                        304 * 304, 608 * 608, 1 << 20, (1 << 20) + 7, 65521, 2147483647, 1 << 30]
+    for d in divisors:
+        xs = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, 7 * d + 3, 2147483647, 2147483646, 2147483647 - d] + [int(v) for v in rng.integers(0, 2**31 - 1, 24)]
+        for x in xs:
+            if 0 <= x < 2**31:
+                assert _hip.lib.y3_debug_div(x, d) == x // d, (x, d)
+    # planner-level consequence: the number of row tiles the epilogue statistics are written for is a host-side query
+    t = _hip.Tensor(0, 8, 52, 52, 256, 256)
+    s = _hip.Tensor(0, 8, 52, 52, 128, 128)
+    assert _hip.lib.y3_conv2d_dgrad_bn_tiles(t, 3, 1, s) == (8 * 52 * 52 + 63) // 64
+    assert _hip.lib.y3_conv2d_dgrad_bn_tiles(t, 3, 2, s) == 0          # stride 2 does not qualify
+    assert _hip.lib.y3_bn_bwd_workspace(8 * 52 * 52, 256) > 1024 and _hip.lib.y3_bn_bwd_workspace(100, 6) == 0
+
+
 def test_model_refuses_to_run_without_gpu():
     """The product has no CPU fallback: constructing the model without a HIP device raises."""
     if torch.cuda.is_available():
