@@ -32,3 +32,13 @@ for _ in range(10):
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats('tottime').print_stats(18)
+
+# one step at a time, queue drained before each: the host cost of a step without back-pressure from a full queue
+ts = []
+for _ in range(5):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    y.train_step((x, gts))
+    ts.append((time.perf_counter() - t) * 1e3)
+    torch.cuda.synchronize()
+print('host issue, one step with an empty queue: %s ms' % ['%.2f' % v for v in ts])
