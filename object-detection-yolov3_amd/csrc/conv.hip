@@ -266,8 +266,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
 }
 
 // ---------------------------------------------------------------------------
-// Fast path of the same gather-GEMM (taken when C % BK == 0 and Nout % 4 == 0, i.e. every layer except
-// the first conv and the 14-channel heads): a K step never straddles a tap, so the tap and the channel
+// Fast path of the same gather-GEMM (taken when C % BK == 0, i.e. every layer except the first conv; the 14-channel
+// heads included -- see make_fast): a K step never straddles a tap, so the tap and the channel
 // base are wave-uniform and travel in the scalar offset of buffer loads; per-lane offsets are loop
 // invariant; padding / tile-edge lanes are pointed past the descriptor's range and read zeros from the
 // hardware bounds check instead of branching.
