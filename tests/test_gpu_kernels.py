@@ -300,6 +300,8 @@ def test_conv_dgrad_bn_epilogue_stats(hip, shape, accum):
     computes from the finished gradient (fp32 tile sums vs fp64 running sums: 2e-5 of the largest value per quantity;
     dbias is a difference of such sums, compared at 1e-4 of sum|dz| like test_batchnorm_train_fwd_bwd)."""
     from util import nhwc_buf, stream, assert_close
+    if os.environ.get('Y3_NO_FAST'):
+        pytest.skip('the epilogue statistics live in the fast kernel only (Y3_NO_FAST is set: y3_conv2d_dgrad_bn_tiles() == 0, the model falls back to y3_bn_bwd_stats)')
     n, h, w, cin, cout, k = shape          # conv cin -> cout; its data gradient has cin channels
     g = torch.Generator().manual_seed(cin * 3 + cout + k)
     dy = torch.randn(n, h, w, cout, generator=g)
