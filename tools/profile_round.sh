@@ -1,6 +1,8 @@
 #!/bin/bash
 # Refresh the judged measurements of a round on the GPU box:  bash tools/profile_round.sh r01
 # Writes under gpurun_out/<tag>/ ; copy the summaries into profiles/ afterwards (tools/traffic_summary.py for the PMC passes).
+# bench.py reads profiles/<tag>_traffic.json for roofline.traffic: after a conv change, copy the new traffic.json first and run
+# bench.py once more for the committed bench line.
 set -e -o pipefail
 TAG=${1:-r02}
 OUT=gpurun_out/$TAG
@@ -16,6 +18,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv
 echo "write done"
 python tools/traffic_summary.py $(find $OUT/fetch -name "*counter_collection.csv") $(find $OUT/write -name "*counter_collection.csv") 6 > $OUT/traffic.json
 python tools/layer_times.py > $OUT/layer_times.txt 2>&1
+python tools/infer_bench.py --layers > $OUT/infer_bench.txt 2>&1
 python tools/trace_union.py $(find $OUT/stats -name "*kernel_trace.csv") > $OUT/trace_union.json
 # MFMA utilisation of the shipping conv kernels: one counter pass over the per-shape driver (program directly after --)
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc -o p --output-format csv -- python3 tools/conv_tune.py > $OUT/pmc_conv_tune.txt 2> $OUT/rocprof_pmc.err
