@@ -91,9 +91,10 @@ size_t y3_conv2d_dgrad_workspace(const y3_tensor* ddst, int ksize, int stride, c
 /*
  * y3_conv2d_dgrad whose epilogue also sums the six raw moments of (dsrc after this launch, bn_a) per output column and
  * row tile -- the statistics of the BatchNorm backward of the layer that PRODUCED dsrc's activation (bn_a = that layer's
- * lrelu(z), geometry of dsrc).  Use it for the launch that completes dsrc (the last accumulation).  Stride 1 and fast-path
- * channel counts only: y3_conv2d_dgrad_bn_tiles() returns the number of row tiles (partials: tiles * 6 * dsrc->c floats,
- * 16-byte aligned), or 0 when the shape does not qualify.  Same workspace as y3_conv2d_dgrad.
+ * lrelu(z), geometry of dsrc).  Use it for the launch that completes dsrc (the last accumulation).  Fast-path channel
+ * counts only; stride 2 (3x3) only when the four parity classes go out as one merged launch: y3_conv2d_dgrad_bn_tiles()
+ * returns the number of partial rows (row tiles, over all classes; partials: rows * 6 * dsrc->c floats, 16-byte aligned),
+ * or 0 when the shape does not qualify.  Same workspace as y3_conv2d_dgrad.
  */
 int y3_conv2d_dgrad_bn(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc,
                        unsigned flags, const y3_tensor* bn_a, float* bn_partials,

@@ -315,6 +315,7 @@ struct FastArgs {
     float* bn_part;      // BNS kernels: [row tile][6][Nout] partial raw moments of (dst, bn_a), see bn_bwd_stats_kernel
     unsigned bn_a_bytes;
     int bn_a_ld;
+    int bn_row0;         // BNS: first partial row of this launch / parity class (rows are bn_row0 + row tile)
 };
 
 #define Y3_OOB 0x80000000u
@@ -789,7 +790,6 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
     for (int q = 0; q < (BNS ? 6 : 1); ++q)
 #pragma unroll
         for (int j = 0; j < NB; ++j) bsum[q][j] = 0.f;
-    static_assert(!BNS || DENSE, "BatchNorm-backward statistics are only built for the dense epilogue");
     if constexpr (DENSE) {
         // dense destination (pixel index == m): buffer stores with the row part of the offset in the scalar operand and
         // tile-edge lanes pointed out of range -- no per-element 64-bit address math, no divergent branches.  All 676
@@ -895,6 +895,7 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
         const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid ? p.resid : p.dst), 0,
                                                                                p.resid ? p.resid_bytes : 0u, 0x00020000);
         const bool has_scale = p.scale != nullptr, has_resid = p.resid != nullptr;
+        const __amdgpu_buffer_rsrc_t rs_bna = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNS ? p.bn_a : p.dst), 0, BNS ? p.bn_a_bytes : 0u, 0x00020000);
         unsigned rowpix[MB][16];
 #pragma unroll
         for (int i = 0; i < MB; ++i)
@@ -931,6 +932,17 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
                     if (has_resid)
                         v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, ok ? (rowpix[i][r] * (unsigned)p.resid_ld + (unsigned)n) * 4u : Y3_OOB, 0, 0));
                     if (do_accum) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_dst, vo, 0, 0));
+                    if constexpr (BNS) {      // the same six moments as in the dense epilogue; `a` has the geometry of the strided destination
+                        const float av = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_bna, ok ? (rowpix[i][r] * (unsigned)p.bn_a_ld + (unsigned)n) * 4u : Y3_OOB, 0, 0));
+                        const float dv = ok ? v : 0.f;
+                        const bool pos = av > 0.f;
+                        bsum[0][j] += dv;
+                        bsum[1][j] += dv * av;
+                        bsum[2][j] += pos ? dv : 0.f;
+                        bsum[3][j] += pos ? av : 0.f;
+                        bsum[4][j] += pos ? 1.f : 0.f;
+                        bsum[5][j] += av;
+                    }
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_dst, vo, 0, 0);
                 }
             }
@@ -953,7 +965,7 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
 #pragma unroll
             for (int w = 0; w < WM; ++w) s += red[which][w][col];
             const int n = n0 + col;
-            if (n < p.Nout) p.bn_part[((long long)bm * 6 + which) * p.Nout + n] = s;
+            if (n < p.Nout) p.bn_part[((long long)(p.bn_row0 + bm) * 6 + which) * p.Nout + n] = s;
         }
     } else if (p.stats) {
 #pragma unroll
@@ -995,12 +1007,12 @@ struct FastArgs4 {
     FastArgs a[4];
     int first[5];
 };
-template <int BM, int BN, int WM, int WN, int BK>
+template <int BM, int BN, int WM, int WN, int BK, bool BNS = false>
 __global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_multi_kernel(const FastArgs4 m) {
     int c = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i) c += ((int)blockIdx.x >= m.first[i]) ? 1 : 0;
-    conv_fast_body<BM, BN, WM, WN, BK, false, 2>(m.a[c], (int)blockIdx.x - m.first[c], m.first[c + 1] - m.first[c]);
+    conv_fast_body<BM, BN, WM, WN, BK, false, 2, BNS>(m.a[c], (int)blockIdx.x - m.first[c], m.first[c + 1] - m.first[c]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1652,7 +1664,8 @@ static bool make_fast(const ConvArgs& a, int ntaps, int bk, FastArgs* f) {
     p.bn_a = a.bn_a;
     p.bn_part = a.bn_part;
     p.bn_a_ld = a.bn_a_ld;
-    p.bn_a_bytes = a.bn_a ? (unsigned)((long long)a.M * a.bn_a_ld * 4) : 0u;
+    p.bn_a_bytes = a.bn_a ? (unsigned)((a.dense_dst ? (long long)a.M : (long long)a.src_n * a.DH * a.DW) * a.bn_a_ld * 4) : 0u;
+    p.bn_row0 = 0;
     p.H = a.H;
     p.W = a.W;
     p.logC = a.logC;
@@ -1849,7 +1862,8 @@ extern "C" size_t y3_conv2d_dgrad_workspace(const y3_tensor* ddst, int ksize, in
 
 // One launch for all parity classes of a stride-2 data gradient; false if the shapes do not qualify (the caller then
 // launches the classes one by one).
-static bool launch_dgrad_multi(const ConvArgs* cls, int ncls, hipStream_t st) {
+// dry != nullptr: nothing is launched, *dry receives the number of partial-statistics rows (row tiles over all classes)
+static bool launch_dgrad_multi(const ConvArgs* cls, int ncls, hipStream_t st, int* dry = nullptr) {
     static const int off = env_int("Y3_NO_DGRAD_MULTI", 0);
     if (off || ncls < 2 || ncls > 4) return false;
     FastArgs4 m = {};
@@ -1860,7 +1874,7 @@ static bool launch_dgrad_multi(const ConvArgs* cls, int ncls, hipStream_t st) {
     TileCfg t = pick_tile(mmax * ncls, cls[0].Nout);   // the classes share one grid: size the tile for their sum
     if (t.bm == 128 && t.bn == 128) t.bm = 64;   // the 128x128 instantiation of the merged kernel spills (four argument sets live)
     if (t.bk != 16) return false;
-    int first = 0;
+    int first = 0, rows = 0;
     for (int c = 0; c < ncls; ++c) {
         const int ntaps = cls[c].K / cls[c].C;
         if (!fast_shape_ok(cls[c].C, cls[c].Nout, cls[c].K, ntaps) || !make_fast(cls[c], ntaps, t.bk, &m.a[c])) return false;
@@ -1877,11 +1891,27 @@ static bool launch_dgrad_multi(const ConvArgs* cls, int ncls, hipStream_t st) {
         m.a[c].slab = nullptr;
         m.a[c].tickets = nullptr;
         m.a[c].stagger = 0;
+        m.a[c].bn_row0 = rows;
+        rows += m.a[c].nbm;
         m.first[c] = first;
         first += y3_cdiv(cls[c].M, t.bm) * m.a[c].nbn;
     }
     for (int c = ncls; c <= 4; ++c) m.first[c] = first;
     const int key = t.bm * 1000 + t.bn;
+    if (dry) {
+        *dry = rows;
+        return key == 128 * 1000 + 64 || key == 128 * 1000 + 32 || key == 64 * 1000 + 64 || key == 64 * 1000 + 128;
+    }
+    if (cls[0].bn_a) {
+        switch (key) {
+            case 128 * 1000 + 64: hipLaunchKernelGGL((conv_igemm_fast_multi_kernel<128, 64, 4, 1, 16, true>), dim3(first), dim3(256), 0, st, m); break;
+            case 128 * 1000 + 32: hipLaunchKernelGGL((conv_igemm_fast_multi_kernel<128, 32, 4, 1, 16, true>), dim3(first), dim3(256), 0, st, m); break;
+            case 64 * 1000 + 64: hipLaunchKernelGGL((conv_igemm_fast_multi_kernel<64, 64, 2, 2, 16, true>), dim3(first), dim3(256), 0, st, m); break;
+            case 64 * 1000 + 128: hipLaunchKernelGGL((conv_igemm_fast_multi_kernel<64, 128, 2, 2, 16, true>), dim3(first), dim3(256), 0, st, m); break;
+            default: return false;
+        }
+        return true;
+    }
     switch (key) {
         case 128 * 1000 + 64: hipLaunchKernelGGL((conv_igemm_fast_multi_kernel<128, 64, 4, 1, 16>), dim3(first), dim3(256), 0, st, m); break;
         case 128 * 1000 + 32: hipLaunchKernelGGL((conv_igemm_fast_multi_kernel<128, 32, 4, 1, 16>), dim3(first), dim3(256), 0, st, m); break;
@@ -1893,7 +1923,8 @@ static bool launch_dgrad_multi(const ConvArgs* cls, int ncls, hipStream_t st) {
 }
 
 static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc, unsigned flags,
-                             const y3_tensor* bn_a, float* bn_partials, void* workspace, size_t workspace_bytes, y3_stream_t stream);
+                             const y3_tensor* bn_a, float* bn_partials, void* workspace, size_t workspace_bytes, y3_stream_t stream,
+                             int* dry_rows = nullptr);
 
 extern "C" int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc, unsigned flags,
                                void* workspace, size_t workspace_bytes, y3_stream_t stream) {
@@ -1903,7 +1934,14 @@ extern "C" int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksi
 // Row tiles of the partial statistics y3_conv2d_dgrad_bn writes for this shape, 0 if the shape does not qualify (stride 2,
 // channel counts off the fast path): the caller then runs y3_bn_bwd_stats on the finished gradient instead.
 extern "C" int y3_conv2d_dgrad_bn_tiles(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc) {
-    if (!ddst || !dsrc || stride != 1 || (ksize != 1 && ksize != 3)) return 0;
+    if (!ddst || !dsrc || (ksize != 1 && ksize != 3)) return 0;
+    if (stride == 2) {      // the merged launch of the four parity classes: rows of all classes, or 0 if it would not be taken
+        if (ksize != 3 || ddst->h != (dsrc->h + 1) / 2 || ddst->w != (dsrc->w + 1) / 2 || ddst->n != dsrc->n) return 0;
+        int rows = 0;
+        if (conv2d_dgrad_impl(ddst, nullptr, ksize, 2, dsrc, 0, nullptr, nullptr, nullptr, 0, nullptr, &rows) != Y3_OK) return 0;
+        return rows;
+    }
+    if (stride != 1) return 0;
     const int taps = ksize * ksize, K = taps * ddst->c, M = dsrc->n * dsrc->h * dsrc->w;
     if (!fast_shape_ok(ddst->c, dsrc->c, K, taps)) return 0;
     const ConvPlan pl = plan_conv(M, dsrc->c, K, true);
@@ -1922,10 +1960,13 @@ extern "C" int y3_conv2d_dgrad_bn(const y3_tensor* ddst, const float* wt_t, int 
 }
 
 static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc, unsigned flags,
-                             const y3_tensor* bn_a, float* bn_partials, void* workspace, size_t workspace_bytes, y3_stream_t stream) {
-    if (int e = check_tensor(ddst, "conv2d_dgrad ddst")) return e;
-    if (int e = check_tensor(dsrc, "conv2d_dgrad dsrc")) return e;
-    Y3_CHECK_ARG(wt_t, "conv2d_dgrad: null weights");
+                             const y3_tensor* bn_a, float* bn_partials, void* workspace, size_t workspace_bytes, y3_stream_t stream,
+                             int* dry_rows) {
+    if (!dry_rows) {      // dry run (y3_conv2d_dgrad_bn_tiles, stride 2): geometry only, pointers may be null
+        if (int e = check_tensor(ddst, "conv2d_dgrad ddst")) return e;
+        if (int e = check_tensor(dsrc, "conv2d_dgrad dsrc")) return e;
+        Y3_CHECK_ARG(wt_t, "conv2d_dgrad: null weights");
+    }
     Y3_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_dgrad: ksize %d unsupported", ksize);
     Y3_CHECK_ARG(stride == 1 || stride == 2, "conv2d_dgrad: stride %d unsupported", stride);
     const int OH = (dsrc->h + stride - 1) / stride, OW = (dsrc->w + stride - 1) / stride;
@@ -1973,7 +2014,6 @@ static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize
         }
         return launch_igemm(p, workspace, workspace_bytes, (hipStream_t)stream);
     }
-    Y3_CHECK_ARG(!bn_a, "conv2d_dgrad_bn: stride 2 is not supported");
     // stride 2: forward out o reads in[2o + k - pad]; input pixel i = 2q + par receives from the taps with
     // (par + pad - k) even, at o = q + (par + pad - k)/2.  One launch per (row parity, col parity).
     ConvArgs cls[4];
@@ -2011,6 +2051,11 @@ static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize
                 p.cmask = 0x7fffffff;
             }
             p.K = nt * ddst->c;
+            if (bn_a) {
+                p.bn_a = bn_a->ptr;
+                p.bn_a_ld = bn_a->ld;
+                p.bn_part = bn_partials;
+            }
             cls[ncls++] = p;
         }
     // longest contraction first, so that the 4-tap workgroups of a merged launch start before the 1-tap ones
@@ -2020,10 +2065,17 @@ static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize
             cls[j] = cls[j - 1];
             cls[j - 1] = tmp;
         }
+    if (dry_rows) {
+        *dry_rows = 0;
+        int rows = 0;
+        if (launch_dgrad_multi(cls, ncls, (hipStream_t)stream, &rows)) *dry_rows = rows;
+        return Y3_OK;
+    }
     if (launch_dgrad_multi(cls, ncls, (hipStream_t)stream)) {
         Y3_CHECK_LAUNCH("conv_igemm_fast_multi");
         return Y3_OK;
     }
+    Y3_CHECK_ARG(!bn_a, "conv2d_dgrad_bn: the merged stride-2 launch is not available for this shape");
     for (int c = 0; c < ncls; ++c)
         if (int e = launch_igemm(cls[c], workspace, workspace_bytes, (hipStream_t)stream)) return e;
     return Y3_OK;

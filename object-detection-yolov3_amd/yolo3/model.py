@@ -23,6 +23,7 @@ from ._hip import lib, check, view, EPI_LRELU, EPI_ACCUM
 BN_EPS = 1e-3          # Keras BatchNormalization defaults
 BN_MOMENTUM = 0.99
 BN_EPILOGUE_STATS = os.environ.get('Y3_BN_EPI', '1') != '0'   # BatchNorm-backward statistics from the epilogue of the data gradient that completes dy
+BN_EPILOGUE_WIDE = os.environ.get('Y3_BN_EPI_WIDE', '1') != '0'   # ... also when the consumer is a stride-2 convolution or reads a concat slice
 LRELU_ALPHA = 0.2      # tf.nn.leaky_relu default (App. C3)
 ALIGN = 64             # arena alignment in floats (256 B)
 
@@ -419,8 +420,8 @@ class _Plan:
 
         # BatchNorm-backward statistics without a pass of their own: the gradient dy of a layer's output is complete when the
         # data gradient of its FIRST consumer in forward order has run (later consumers -- residual adds, routes -- are
-        # visited earlier by the reversed walk).  If that consumer is a stride-1 convolution reading exactly this tensor
-        # and the shape qualifies (y3_conv2d_dgrad_bn_tiles), its data gradient sums the raw moments in its epilogue and
+        # visited earlier by the reversed walk).  If that consumer is a convolution reading exactly this tensor and the
+        # shape qualifies (y3_conv2d_dgrad_bn_tiles; stride 2: the merged launch), its data gradient sums the raw moments in its epilogue and
         # the producer only needs y3_bn_bwd_finalize_tiles; every other layer keeps y3_bn_bwd_stats.
         epi_of = {}            # id(consumer op) -> (producer activation a, partial buffer, tiles)
         epi_for = {}           # id(producer op) -> (partial buffer, tiles)
@@ -445,7 +446,9 @@ class _Plan:
                     continue
                 _, i, src, a, y, resid, _ = op
                 cons = first_consumer.get(id(y))
-                if cons is None or cons[0] != 'conv_layer' or cons[2] is not y or y.parent is not None or y.children or y is self.x0:
+                if cons is None or cons[0] != 'conv_layer' or cons[2] is not y or y.children or y is self.x0:
+                    continue      # (a concat SLICE qualifies: later readers of the whole concat are visited earlier by the reversed walk)
+                if not BN_EPILOGUE_WIDE and (y.parent is not None or specs[cons[1]].s != 1):
                     continue
                 csp = specs[cons[1]]
                 ca = cons[3]

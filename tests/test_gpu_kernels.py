@@ -292,7 +292,8 @@ def test_conv_dgrad(hip, case, accum):
     assert_close(dsv.cpu(), ref, rtol=2e-5, what='dgrad')
 
 
-@pytest.mark.parametrize('shape', [(8, 13, 13, 512, 1024, 3), (8, 26, 26, 128, 256, 1), (2, 52, 52, 64, 128, 3), (8, 52, 52, 128, 256, 3), (1, 13, 15, 64, 32, 1)])
+@pytest.mark.parametrize('shape', [(8, 13, 13, 512, 1024, 3), (8, 26, 26, 128, 256, 1), (2, 52, 52, 64, 128, 3), (8, 52, 52, 128, 256, 3), (1, 13, 15, 64, 32, 1),
+                                   (2, 104, 104, 64, 128, 3, 2), (8, 26, 26, 256, 512, 3, 2), (1, 30, 26, 32, 64, 3, 2)])
 @pytest.mark.parametrize('accum', [False, True])
 def test_conv_dgrad_bn_epilogue_stats(hip, shape, accum):
     """y3_conv2d_dgrad_bn: the data gradient is bit-identical to y3_conv2d_dgrad's, and the per-row-tile partial moments
@@ -302,36 +303,38 @@ def test_conv_dgrad_bn_epilogue_stats(hip, shape, accum):
     from util import nhwc_buf, stream, assert_close
     if os.environ.get('Y3_NO_FAST'):
         pytest.skip('the epilogue statistics live in the fast kernel only (Y3_NO_FAST is set: y3_conv2d_dgrad_bn_tiles() == 0, the model falls back to y3_bn_bwd_stats)')
-    n, h, w, cin, cout, k = shape          # conv cin -> cout; its data gradient has cin channels
+    n, h, w, cin, cout, k = shape[:6]      # conv cin -> cout; its data gradient has cin channels (h, w: the conv's INPUT size)
+    s_ = shape[6] if len(shape) > 6 else 1   # stride 2: the merged launch of the four parity classes carries the statistics
+    oh, ow = -(-h // s_), -(-w // s_)
     g = torch.Generator().manual_seed(cin * 3 + cout + k)
-    dy = torch.randn(n, h, w, cout, generator=g)
+    dy = torch.randn(n, oh, ow, cout, generator=g)
     wk = torch.randn(k, k, cin, cout, generator=g) * 0.05
     a = torch.randn(n, h, w, cin, generator=g)            # activation of the layer that produced the conv's input
     a = torch.where(a > 0, a, 0.2 * a)
     init = torch.randn(n, h, w, cin, generator=g)
-    _, ddv = nhwc_buf(n, h, w, cout)
+    _, ddv = nhwc_buf(n, oh, ow, cout)
     ddv.copy_(dy)
     _, av = nhwc_buf(n, h, w, cin, ld=cin + 8)
     av.copy_(a)
     wt = wk.permute(0, 1, 3, 2).contiguous().cuda()
-    DD, A = hip.Tensor(ddv.data_ptr(), n, h, w, cout, cout), hip.Tensor(av.data_ptr(), n, h, w, cin, cin + 8)
+    DD, A = hip.Tensor(ddv.data_ptr(), n, oh, ow, cout, cout), hip.Tensor(av.data_ptr(), n, h, w, cin, cin + 8)
     outs = []
     for fused in (False, True):
         _, dsv = nhwc_buf(n, h, w, cin, ld=cin + 4, fill=0.0)
         if accum:
             dsv.copy_(init)
         DS = hip.Tensor(dsv.data_ptr(), n, h, w, cin, cin + 4)
-        wsb = int(hip.lib.y3_conv2d_dgrad_workspace(DD, k, 1, DS))
+        wsb = int(hip.lib.y3_conv2d_dgrad_workspace(DD, k, s_, DS))
         ws = torch.zeros(wsb // 4 + 4, device='cuda')
         flags = hip.EPI_ACCUM if accum else 0
         if fused:
-            tiles = int(hip.lib.y3_conv2d_dgrad_bn_tiles(DD, k, 1, DS))
+            tiles = int(hip.lib.y3_conv2d_dgrad_bn_tiles(DD, k, s_, DS))
             assert tiles > 0
             part = torch.full((tiles * 6 * cin,), float('nan'), device='cuda')
-            hip.check(hip.lib.y3_conv2d_dgrad_bn(DD, wt.data_ptr(), k, 1, DS, flags, A, part.data_ptr(), ws.data_ptr(), wsb, stream()))
+            hip.check(hip.lib.y3_conv2d_dgrad_bn(DD, wt.data_ptr(), k, s_, DS, flags, A, part.data_ptr(), ws.data_ptr(), wsb, stream()))
             assert not torch.isnan(part).any()
         else:
-            hip.check(hip.lib.y3_conv2d_dgrad(DD, wt.data_ptr(), k, 1, DS, flags, ws.data_ptr(), wsb, stream()))
+            hip.check(hip.lib.y3_conv2d_dgrad(DD, wt.data_ptr(), k, s_, DS, flags, ws.data_ptr(), wsb, stream()))
         outs.append(dsv.clone().contiguous())
     assert torch.equal(outs[0], outs[1]), 'dgrad_bn changed the data gradient'
     M = n * h * w
