@@ -66,7 +66,10 @@ def test_index_decode_division_is_exact():
     t = _hip.Tensor(0, 8, 52, 52, 256, 256)
     s = _hip.Tensor(0, 8, 52, 52, 128, 128)
     assert _hip.lib.y3_conv2d_dgrad_bn_tiles(t, 3, 1, s) == (8 * 52 * 52 + 63) // 64
-    assert _hip.lib.y3_conv2d_dgrad_bn_tiles(t, 3, 2, s) == 0          # stride 2 does not qualify
+    assert _hip.lib.y3_conv2d_dgrad_bn_tiles(t, 3, 2, s) == 0          # not a stride-2 geometry (ddst must be half of dsrc)
+    t2 = _hip.Tensor(0, 8, 26, 26, 256, 256)
+    rows = _hip.lib.y3_conv2d_dgrad_bn_tiles(t2, 3, 2, s)               # merged launch of the four parity classes: 4 x 5 408 pixels
+    assert rows > 0 and rows % 4 == 0 and rows * 128 >= 4 * 5408 > (rows - 4) * 64
     assert _hip.lib.y3_bn_bwd_workspace(8 * 52 * 52, 256) > 1024 and _hip.lib.y3_bn_bwd_workspace(100, 6) == 0
 
 
