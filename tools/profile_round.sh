@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv
 echo "fetch done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-inference > $OUT/bench_write.json 2> $OUT/rocprof_write.err
 echo "write done"
-python tools/traffic_summary.py $(find $OUT/fetch -name "*counter_collection.csv") $(find $OUT/write -name "*counter_collection.csv") 6 > $OUT/traffic.json
+python tools/traffic_summary.py $(find $OUT/fetch -name "*counter_collection.csv") $(find $OUT/write -name "*counter_collection.csv") > $OUT/traffic.json
 python tools/layer_times.py > $OUT/layer_times.txt 2>&1
 python tools/infer_bench.py --layers > $OUT/infer_bench.txt 2>&1
 python tools/trace_union.py $(find $OUT/stats -name "*kernel_trace.csv") > $OUT/trace_union.json
