@@ -198,28 +198,60 @@ def cpu_baseline(seed, budget_s=25.0):
                        '%d step(s) at batch %d, 416x416, %.1f s' % (steps, bs, t))
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, timeout_s=1500.0):
     """`python bench.py --gpus N` outside a launcher: start N fresh rank processes of this script (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set) and relay rank 0's JSON line.
-    This process has not touched the GPU (importing torch does not initialise HIP) and never does: it only waits."""
+    This process has not touched the GPU (importing torch does not initialise HIP) and never does: it only waits.  Every
+    child writes to a file of its own (no pipe can fill up); all children are polled, and when one exits non-zero -- or the
+    time limit passes -- the others are terminated instead of sitting in the rendezvous timeout."""
     import socket
     import subprocess
+    import tempfile
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    tmp = tempfile.mkdtemp(prefix='y3bench_')
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    out0 = procs[0].communicate()[0]
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+        out = open(os.path.join(tmp, 'rank%d.out' % r), 'w')
+        err = open(os.path.join(tmp, 'rank%d.err' % r), 'w')
+        logs.append((out, err))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, stderr=err))
+    deadline = time.time() + timeout_s
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [i for i, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = 'rank %d exited with code %d' % (bad[0], codes[bad[0]])
+        elif time.time() > deadline:
+            failed = 'time limit of %.0f s passed' % timeout_s
+        if failed or all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    for out, err in logs:
+        out.close()
+        err.close()
+    sys.stdout.write(open(os.path.join(tmp, 'rank0.out')).read())
     sys.stdout.flush()
-    if any(codes):
-        raise SystemExit('rank exit codes %s' % codes)
+    if failed:
+        for r in range(n):
+            tail = open(os.path.join(tmp, 'rank%d.err' % r)).read()[-1500:]
+            if tail:
+                sys.stderr.write('--- rank %d stderr (tail) ---\n%s\n' % (r, tail))
+        raise SystemExit('bench ranks failed: %s (exit codes %s)' % (failed, [p.returncode for p in procs]))
 
 
 def main():
@@ -236,6 +268,8 @@ def main():
     ap.add_argument('--bucket-mb', type=float, default=32.0)
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument('--check-replicas', action='store_true', help='after the run, verify that every rank holds identical weights')
+    ap.add_argument('--transport', default='torch', choices=['torch', 'native'], help="gradient all-reduce through torch.distributed (default) or RCCL called directly through the C ABI (y3_comm_*)")
+    ap.add_argument('--force-collective', action='store_true', help='(rehearsal) with one rank: initialise the process group anyway and all-reduce every bucket')
     args = ap.parse_args()
     if args.tiled_only:
         torch.cuda.set_device(0)
@@ -255,15 +289,26 @@ def main():
     torch.cuda.set_device(local_rank % max(1, ndev))
     import torch.distributed as dist
     from yolo3.model import YoloV3
+    from yolo3 import streams
+    streams.reserve()          # the step's side / comm streams take their hardware queues before RCCL creates its own (yolo3/streams.py)
     strategy = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if world == 1:
+            import socket
+            s_ = socket.socket()
+            s_.bind(('127.0.0.1', 0))
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', str(s_.getsockname()[1]))
+            s_.close()
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank % max(1, ndev)))
         else:
             dist.init_process_group(args.backend)
         from yolo3.parallel import DataParallel
-        strategy = DataParallel(bucket_mb=args.bucket_mb)
+        strategy = DataParallel(bucket_mb=args.bucket_mb, force_collective=args.force_collective, transport=args.transport)
 
     global_batch = BATCH * world
     use_graph = args.graph and not args.no_graph and world == 1
@@ -279,7 +324,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if strategy is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -299,6 +344,19 @@ def main():
     t_issued = time.perf_counter() - t1
     barrier()
     del loss_extra
+    comm = None
+    if strategy is not None:
+        # one instrumented step (outside the timed region): HIP events around every bucket's all-reduce on the comm stream and
+        # around the compute stream's wait in finish_step -- how long the collectives ran, and how much of that the compute
+        # stream actually waited for (the exposed, un-overlapped part)
+        strategy.collect_stats = True
+        yolo.dist_train_step(strategy, inputs)
+        barrier()
+        st_ = strategy.step_stats() or {}
+        strategy.collect_stats = False
+        comm = strategy.comm_info()
+        comm.update(st_)
+        comm['payload_mb_per_step'] = sum(hi - lo for lo, hi, _ in strategy.buckets) * 4 / 1e6
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -359,7 +417,28 @@ def main():
             bbox_utils.nms_device(rows, 32.0, clip_wh=(IMG, IMG))
         torch.cuda.synchronize()
         t_nms = (time.perf_counter() - t1) / n_inf
+        # the HBM-bound tail of the path on its own (north_star: "achieved HBM GB/s for the decode/NMS path"): HIP events on
+        # the launch stream around y3_decode_fwd and y3_nms_per_class, 50 launches each; algorithmic bytes per SURVEY 8d
+        # (decode reads and writes N*Nb*(5+K)*4 B, NMS reads the same rows); rocprofv3 figures: profiles/r03_hbm_path.md
+        iplan = yolo._plan(BATCH, False)
+        cur = torch.cuda.current_stream()
+
+        def ev_us(fn, reps=50):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            for _ in range(reps):
+                fn()
+            e1.record(cur)
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / reps
+        decode_us = ev_us(lambda: iplan.run_decode(cur.cuda_stream))
+        nms_us = ev_us(lambda: bbox_utils.nms_device(rows, 32.0, clip_wh=(IMG, IMG)))
+        row_bytes = BATCH * rows.shape[1] * rows.shape[2] * 4
         infer = {'images_per_s_forward_decode': BATCH / t_fwd, 'ms_forward_decode': t_fwd * 1e3, 'ms_nms_batch8': t_nms * 1e3, 'launch': 'hip-graph',
+                 'decode_us': decode_us, 'decode_gbps': 2 * row_bytes / decode_us / 1e3, 'nms_us': nms_us, 'nms_gbps': row_bytes / nms_us / 1e3,
+                 'decode_nms_bytes': {'rows_bytes': row_bytes, 'decode': '2 x rows (read feature maps, write rows)', 'nms': '1 x rows + keep lists',
+                                      'note': '1.6 MB per launch: launch / latency bound, far below the 8 TB/s HBM peak by construction; us is the figure to compare'},
                  'forward_tflops': fwd_fl * BATCH / t_fwd / 1e12, 'forward_frac_of_fp32_mfma_peak': fwd_fl * BATCH / t_fwd / 1e12 / FP32_MFMA_PEAK_TFLOPS}
         # the same batch on the bf16 conv path (v_mfma_f32_32x32x16_bf16, fp32 accumulate / heads / decode / NMS)
         for _ in range(3):
@@ -421,13 +500,16 @@ def main():
             out['inference_bs8_bf16'] = infer16
         if tiled is not None:
             out['tiled_4k_608'] = tiled
+        if comm is not None:
+            out['comm'] = comm
         if world > 1:
             out['config']['backend'] = args.backend
             out['replicas_identical'] = True if args.check_replicas else None
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(seed=1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if strategy is not None:
+        strategy.close()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -76,6 +76,12 @@ int y3_conv2d_fwd(const y3_tensor* src, const float* wt, const float* bias, int 
  * the split (forward / data gradient) or is an error (kernel gradient). */
 int y3_conv2d_stats_tiles(int m, int cin, int ksize, int cout);
 size_t y3_conv2d_fwd_workspace(int m, int cin, int ksize, int cout);
+/* Diagnostics (host only, no launch): the plan y3_conv2d_fwd and the stride-1 y3_conv2d_dgrad use for an implicit GEMM of
+ * m x cout x (ksize^2 * cin).  out13 = {bm, bn, bk, tiles, f, s0, s1, chunk0, chunk1, grid, stats_tiles, fast, nk}: tiles
+ * [0, f) are cut into s0 K slices of chunk0 K steps, tiles [f, tiles) into s1 of chunk1 (nk K steps in all); grid = work
+ * items = workgroups.  Returns the workspace bytes (= y3_conv2d_fwd_workspace).  tests/planner_sweep.cpp replays the
+ * kernel's item -> (tile, slice, slab, ticket) mapping from these numbers under AddressSanitizer. */
+size_t y3_conv2d_plan(int m, int cin, int ksize, int cout, int* out13);
 
 /*
  * Gradient w.r.t. the conv input (tape.gradient, model.py:496):
@@ -109,6 +115,10 @@ int y3_conv2d_dgrad_bn_tiles(const y3_tensor* ddst, int ksize, int stride, const
 int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride,
                     float* dw, void* workspace, size_t workspace_bytes, y3_stream_t stream);
 size_t y3_conv2d_wgrad_workspace(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride);
+/* Diagnostics: the kernel-gradient plan for m output pixels.  out8 = {bkr, bn, splits, chunk, tiles, in_kernel, grid,
+ * pixel_table}: the m pixels are cut into `splits` runs of `chunk`; in_kernel = 1 when the last split of a tile reduces
+ * the slabs inside the kernel (splits <= 8), else slab_reduce_kernel follows.  Returns the workspace bytes. */
+size_t y3_conv2d_wgrad_plan(int m, int cin, int ksize, int cout, int* out8);
 
 /* wt_t[tap][co][ci] = wt[tap][ci][co] */
 int y3_transpose_weights(const float* wt, float* wt_t, int taps, int cin, int cout, y3_stream_t stream);
@@ -279,10 +289,15 @@ int y3_tile_gather(const void* img, int dtype, int height, int width, int channe
  * One process per GPU; SUM over the replicas (the loss is already divided by the global batch, model.py:492).  RCCL over
  * xGMI underneath (librccl.so is opened on first use).  Rank 0 calls y3_comm_unique_id and hands the 128 bytes to the
  * other ranks out of band; every rank then calls y3_comm_init with its HIP device current.  The Python host issues the
- * same collective through torch.distributed (backend "nccl" = RCCL); these are for callers without torch. */
+ * same collective through torch.distributed (backend "nccl" = RCCL) by default and through these entry points with
+ * yolo3.parallel.DataParallel(transport='native') / Y3_DP_TRANSPORT=native (the torch group then only carries the id).
+ * Exercised so far with ONE-rank communicators only (the builder's boxes have one GPU and RCCL refuses two ranks on
+ * one device): N > 1 is first run by the driver's multi-GPU bench, with the default torch transport.
+ * y3_comm_info: what the communicator itself reports -- ncclCommCount and ncclGetVersion (-1 where the symbol is missing). */
 int y3_comm_unique_id(void* id128);
 int y3_comm_init(const void* id128, int nranks, int rank, void** comm);
 int y3_allreduce_sum_f32(void* comm, float* buf, size_t count, y3_stream_t stream); /* in place, asynchronous on stream */
+int y3_comm_info(void* comm, int* nranks, int* version);
 int y3_comm_destroy(void* comm);
 
 #ifdef __cplusplus

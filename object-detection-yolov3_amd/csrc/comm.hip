@@ -18,6 +18,8 @@ struct Rccl {
     ncclResult_t (*comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*comm_count)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*get_version)(int*) = nullptr;
     const char* (*error_string)(ncclResult_t) = nullptr;
 };
 Rccl* rccl() {
@@ -34,6 +36,8 @@ Rccl* rccl() {
             r.all_reduce = (decltype(r.all_reduce))dlsym(r.handle, "ncclAllReduce");
             r.comm_destroy = (decltype(r.comm_destroy))dlsym(r.handle, "ncclCommDestroy");
             r.error_string = (decltype(r.error_string))dlsym(r.handle, "ncclGetErrorString");
+            r.comm_count = (decltype(r.comm_count))dlsym(r.handle, "ncclCommCount");
+            r.get_version = (decltype(r.get_version))dlsym(r.handle, "ncclGetVersion");
         }
     }
     const bool ok = r.handle && r.get_unique_id && r.comm_init_rank && r.all_reduce && r.comm_destroy;
@@ -74,6 +78,23 @@ extern "C" int y3_allreduce_sum_f32(void* comm, float* buf, size_t count, y3_str
     Y3_CHECK_ARG(r, "allreduce_sum_f32: librccl.so not found");
     const ncclResult_t rc = r->all_reduce(buf, buf, count, ncclFloat32, ncclSum, (ncclComm_t)comm, (hipStream_t)stream);
     return rc == ncclSuccess ? Y3_OK : fail(r, "ncclAllReduce", rc);
+}
+
+extern "C" int y3_comm_info(void* comm, int* nranks, int* version) {
+    Y3_CHECK_ARG(comm && nranks && version, "comm_info: null pointer");
+    Rccl* r = rccl();
+    Y3_CHECK_ARG(r, "comm_info: librccl.so not found");
+    *nranks = -1;
+    *version = -1;
+    if (r->comm_count) {
+        const ncclResult_t rc = r->comm_count((ncclComm_t)comm, nranks);
+        if (rc != ncclSuccess) return fail(r, "ncclCommCount", rc);
+    }
+    if (r->get_version) {
+        const ncclResult_t rc = r->get_version(version);
+        if (rc != ncclSuccess) return fail(r, "ncclGetVersion", rc);
+    }
+    return Y3_OK;
 }
 
 extern "C" int y3_comm_destroy(void* comm) {

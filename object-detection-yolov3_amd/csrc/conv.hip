@@ -310,7 +310,6 @@ struct FastArgs {
     int sk_slab0;        // first item that owns a slab slot (0, or sk_n0 when only the remainder tiles are split)
     float* slab;
     int* tickets;        // one per tile, zero before the launch
-    int stagger;         // units of 256 cycles by which co-resident workgroups are pushed out of phase before the K loop
     const float* bn_a;   // BNS kernels: activation of the BatchNorm layer whose output gradient this launch completes (dst geometry)
     float* bn_part;      // BNS kernels: [row tile][6][Nout] partial raw moments of (dst, bn_a), see bn_bwd_stats_kernel
     unsigned bn_a_bytes;
@@ -353,7 +352,7 @@ __device__ __forceinline__ void y3_sgb_pairs() {   // COUNT x { MFMAS matrix ins
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool DENSE, int PIPE = 0, bool BNS = false>
+template <int BM, int BN, int WM, int WN, int BK, bool DENSE, bool BNS = false>
 __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw, const int grid) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int LDA = BK + 4;
@@ -513,14 +512,8 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (kend - kbeg) / BK;
-    if (p.stagger > 0) {
-        // Workgroups are dealt to the CUs in launch order: blocks b, b + 256, b + 512 share a CU and start together, run
-        // the same program and would reach their barriers (and leave the matrix pipe idle) together.  Delay the later
-        // generations once so that their K steps interleave (MI355X_MICROARCH.md, two waves per SIMD, item 9).
-        const int gen = ((int)blockIdx.x >> 8) % 3;
-        for (int i = 0; i < gen * p.stagger; ++i) __builtin_amdgcn_s_sleep(4);
-    }
-    if constexpr (PIPE == 2 && BK == 16) {
+    {
+        static_assert(BK == 16, "the hand-interleaved K loop is written for K steps of 16");
         // Software-pipelined K loop, interleaved by hand.  A wave issues MFMAs in order and cannot queue them: once an MFMA
         // has issued, only the 64 cycles it executes are free for other instructions, so memory instructions left in a block
         // between two MFMA groups idle the matrix pipe (measured with tools/probe/conv_timing: 2 758 cycles per step for
@@ -641,91 +634,6 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
             ++ks;
         }
         step(std::false_type{}, std::false_type{}, ks);
-    } else if constexpr (PIPE == 1) {
-        // Software-pipelined K loop.  A wave's only exposed synchronisation per K step is the barrier itself: fragments
-        // of MFMA group g+1 are read from LDS while group g is on the matrix pipe, the barrier sits BEFORE the last
-        // group of the step, and the first fragments of the next step are fetched (from the buffer the barrier just
-        // published) under that last group.  Global loads run two K steps ahead of their use (issued after the barrier,
-        // so its vmcnt(0) never waits for them; stored to LDS one step later).
-        constexpr int NG = BK / 8;
-        static_assert(NG % 2 == 0, "fragment double buffering assumes an even number of MFMA groups per K step");
-        f32x4 fa[2][MB];
-        float fb[2][NB][4];
-        auto ldf = [&](int buf, int g, int set) {
-            const float* as = &As[buf][(wm * TM + l31) * LDA + lh * 4];
-            const float* bs = &Bs[buf][(lh * 4) * BN + wn * TN + l31];
-#pragma unroll
-            for (int i = 0; i < MB; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDA + g * 8);
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) fb[set][j][q] = bs[(g * 8 + q) * BN + j * 32];
-        };
-        auto mma = [&](int set) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < MB; ++i)
-#pragma unroll
-                    for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][q], fb[set][j][q], acc[i][j], 0, 0, 0);
-        };
-        gload(kbeg);
-        lstore(0);
-        __syncthreads();
-        Y3_TSTAMP(1);
-        if (nk > 1) gload(kbeg + BK);
-        Soff nxt = soff_prep(nk > 2 ? kbeg + 2 * BK : kbeg);      // offsets of the loads issued in iteration 0 (K step 2)
-        ldf(0, 0, 0);
-        for (int ks = 0; ks < nk; ++ks) {
-            const int cur = ks & 1;
-#pragma unroll
-            for (int g = 0; g + 1 < NG; ++g) {
-                ldf(cur, g + 1, (g + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(g & 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (ks + 1 < nk && !Y3_ABL(2)) lstore(cur ^ 1);      // every wave finished reading that buffer before the previous barrier
-            if (!Y3_ABL(4)) __syncthreads();
-            if (ks + 2 < nk && !Y3_ABL(1)) gload_at(nxt);
-            if (ks + 1 < nk) ldf(cur ^ 1, 0, 0);
-            nxt = soff_prep(ks + 3 < nk ? kbeg + (ks + 3) * BK : kbeg);   // scalar loads: back before the next barrier
-            __builtin_amdgcn_sched_barrier(0);
-            mma((NG - 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
-    gload(kbeg);
-    lstore(0);
-    __syncthreads();
-    Y3_TSTAMP(1);
-    int cur = 0;
-    for (int ks = 0; ks < nk; ++ks) {
-        const bool more = ks + 1 < nk;
-        if (more && !Y3_ABL(1)) gload(kbeg + (ks + 1) * BK);
-        const float* as = &As[cur][(wm * TM + l31) * LDA + lh * 4];
-        const float* bs = &Bs[cur][(lh * 4) * BN + wn * TN + l31];
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 av[MB];
-            float bv[NB][4];
-#pragma unroll
-            for (int i = 0; i < MB; ++i) av[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDA + kk * 8);
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bv[j][q] = bs[(kk * 8 + q) * BN + j * 32];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < MB; ++i)
-#pragma unroll
-                    for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
-        }
-        if (more && !Y3_ABL(2)) lstore(cur ^ 1);
-        if (!Y3_ABL(4)) __syncthreads();
-        cur ^= 1;
-    }
     }
 
     Y3_TSTAMP(2);
@@ -995,9 +903,9 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
 }
 
 // registers: at least 3 waves per SIMD; the BNS 64x64 variant must also stay at 64 VGPRs (8 waves per SIMD like its plain twin, see `red`)
-template <int BM, int BN, int WM, int WN, int BK, bool DENSE, int PIPE, bool BNS = false>
+template <int BM, int BN, int WM, int WN, int BK, bool DENSE, bool BNS = false>
 __global__ __launch_bounds__(64 * WM * WN, (BNS && BM * BN <= 64 * 64) ? 8 : 3) void conv_igemm_fast_kernel(const FastArgs p) {
-    conv_fast_body<BM, BN, WM, WN, BK, DENSE, PIPE, BNS>(p, (int)blockIdx.x, (int)gridDim.x);
+    conv_fast_body<BM, BN, WM, WN, BK, DENSE, BNS>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Up to four independent gather-GEMMs in ONE launch: the (row parity, column parity) classes of a stride-2 data gradient.
@@ -1012,7 +920,7 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_multi_kernel(
     int c = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i) c += ((int)blockIdx.x >= m.first[i]) ? 1 : 0;
-    conv_fast_body<BM, BN, WM, WN, BK, false, 2, BNS>(m.a[c], (int)blockIdx.x - m.first[c], m.first[c + 1] - m.first[c]);
+    conv_fast_body<BM, BN, WM, WN, BK, false, BNS>(m.a[c], (int)blockIdx.x - m.first[c], m.first[c + 1] - m.first[c]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1276,67 +1184,54 @@ __global__ __launch_bounds__(64 * WM * WN, Y3_WGRAD_WAVES_EU) void conv_wgrad_ke
     __syncthreads();                       // (the reduction below reuses At as a flag word)
 
     if (p.splits > 1 && p.tickets != nullptr) {
-        // Reduction over the pixel splits inside the kernel, as a fixed tree of fan-in Y3_WG_FANIN (bit-reproducible: the
-        // shape of the tree depends on the launch geometry only).  Level by level: park the raw accumulators
-        // (slab[level][tile][index][r4][thread], 16-byte sc1 stores), take the ticket of the group of FANIN neighbours; the
-        // member that draws the group's last ticket sums the group's slabs in index order and carries the sum to the next
-        // level; the others leave.  A flat "last split sums everything" reduction serialises up to ~1 000 slab reads in one
-        // workgroup (measured: kernel gradients 2x slower).  Hand-off rules: see conv_fast_body.
+        // Reduction over the pixel splits inside the kernel (the host takes this path for 2 .. Y3_WG_FANIN splits only): every
+        // split parks its raw accumulators (slab[tile][split][r4][thread], 16-byte sc1 stores) and takes the tile's ticket;
+        // the split that draws the last ticket sums all of them in split order (bit-reproducible whichever split it is) and
+        // writes dw.  With more splits a flat reduction serialises too many slab reads in one workgroup and a tree of such
+        // levels cost more than the streaming slab_reduce_kernel (measured): those launches carry no tickets.
+        // Hand-off rules: see conv_fast_body.
         constexpr int R4 = MB * NB * 4;
         const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x7ffffff0, 0x00020000);
         const unsigned item_bytes = (unsigned)(R4 * THREADS * 16);
         int* flag = reinterpret_cast<int*>(&At[0][0]);
-        int idx = split, count = p.splits;
-        unsigned slab_base = 0;     // items before this level
-        int ticket_base = 0;
-        while (count > 1) {
-            const int groups = (count + Y3_WG_FANIN - 1) / Y3_WG_FANIN;
-            const int group = idx / Y3_WG_FANIN;
-            const int gsize = min(Y3_WG_FANIN, count - group * Y3_WG_FANIN);
-            const unsigned level0 = (slab_base + (unsigned)(bid * count)) * item_bytes + (unsigned)tid * 16u;
-            if (gsize > 1) {
-                const unsigned base = level0 + (unsigned)idx * item_bytes;
+        const int count = p.splits;
+        const unsigned level0 = (unsigned)(bid * count) * item_bytes + (unsigned)tid * 16u;
+        {
+            const unsigned base = level0 + (unsigned)split * item_bytes;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        f32x4 v = {acc[i][j][4 * r], acc[i][j][4 * r + 1], acc[i][j][4 * r + 2], acc[i][j][4 * r + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, base, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                int* tk = p.tickets + bid;
+                const int old = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == count - 1;
+                if (last) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = last;
+            }
+            __syncthreads();
+            if (!*flag) return;
+#pragma unroll 1
+            for (int z = 0; z < count; ++z) {
+                const unsigned base2 = level0 + (unsigned)z * item_bytes;
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
 #pragma unroll
                     for (int j = 0; j < NB; ++j)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            f32x4 v = {acc[i][j][4 * r], acc[i][j][4 * r + 1], acc[i][j][4 * r + 2], acc[i][j][4 * r + 3]};
-                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, base, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
+                            const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, base2, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][j][4 * r + e] = z == 0 ? v[e] : acc[i][j][4 * r + e] + v[e];
                         }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) {
-                    int* tk = p.tickets + ticket_base + bid * groups + group;
-                    const int old = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int last = old == gsize - 1;
-                    if (last) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    *flag = last;
-                }
-                __syncthreads();
-                const int last = *flag;
-                __syncthreads();          // the flag word is rewritten at the next level
-                if (!last) return;
-#pragma unroll 1
-                for (int z = 0; z < gsize; ++z) {
-                    const unsigned base2 = level0 + (unsigned)(group * Y3_WG_FANIN + z) * item_bytes;
-#pragma unroll
-                    for (int i = 0; i < MB; ++i)
-#pragma unroll
-                        for (int j = 0; j < NB; ++j)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, base2, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) acc[i][j][4 * r + e] = z == 0 ? v[e] : acc[i][j][4 * r + e] + v[e];
-                            }
-                }
             }
-            slab_base += (unsigned)(p.tiles * count);
-            ticket_base += p.tiles * groups;
-            idx = group;
-            count = groups;
         }
     }
 
@@ -1441,7 +1336,11 @@ struct TileCfg {
     int bm, bn, bk;
 };
 
-// Tuning override (development only): Y3_TILE="bm,bn,bk" forces one configuration for every launch.
+// Tuning switches.  The product library reads exactly one environment variable on this path, Y3_NO_FAST (generic kernel for
+// every launch; exercised by the GPU tests).  Everything else -- tile override, split-K targets, kernel-gradient plan -- is a
+// development knob of tools/: compiled in with -DY3_DEV only (make DEV=1 -> libyolo3hip_dev.so), constants otherwise.
+#ifdef Y3_DEV
+// Y3_TILE="bm,bn,bk" forces one configuration for every launch.
 static bool tile_override(TileCfg* t) {
     static int state = 0;  // 0 unknown, 1 none, 2 set
     static TileCfg forced;
@@ -1457,6 +1356,12 @@ static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
+static const char* env_str(const char* name) { return getenv(name); }
+#else
+static bool tile_override(TileCfg*) { return false; }
+static int env_int(const char*, int dflt) { return dflt; }
+static const char* env_str(const char*) { return nullptr; }
+#endif
 
 // Tile choice from the measured sweep (tools/conv_tune.py, MI355X): a launch wants >= ~600 workgroups
 // (256 CUs x 2-3 resident); prefer the largest tile that still gives that many, else 64x64 (+ split-K).
@@ -1562,36 +1467,32 @@ extern "C" size_t y3_conv2d_fwd_workspace(int m, int cin, int ksize, int cout) {
     return plan_conv(m, cout, taps * cin, fast_shape_ok(cin, cout, taps * cin, taps)).ws_bytes;
 }
 
+// Diagnostics (include/yolo3hip.h): the plan behind y3_conv2d_fwd / stride-1 y3_conv2d_dgrad for an M x cout x (ksize^2 cin) GEMM
+extern "C" size_t y3_conv2d_plan(int m, int cin, int ksize, int cout, int* out13) {
+    const int taps = ksize * ksize, K = taps * cin;
+    const bool fast = fast_shape_ok(cin, cout, K, taps);
+    const ConvPlan pl = plan_conv(m, cout, K, fast);
+    if (out13) {
+        const int v[13] = {pl.t.bm, pl.t.bn, pl.t.bk, pl.tiles, pl.f, pl.s0, pl.s1, pl.chunk0, pl.chunk1,
+                           pl.f * pl.s0 + (pl.tiles - pl.f) * pl.s1, pl.stats_tiles, fast ? 1 : 0, K / pl.t.bk};
+        for (int i = 0; i < 13; ++i) out13[i] = v[i];
+    }
+    return pl.ws_bytes;
+}
+
 template <int BM, int BN, int WM, int WN, int BK>
 static void launch_cfg(const ConvArgs& p, int grid, hipStream_t st) {
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
 }
 template <int BM, int BN, int WM, int WN, int BK>
 static void launch_fast(const FastArgs& p, bool dense, int grid, hipStream_t st) {
-    static const int pipe = env_int("Y3_PIPE", 2);
     const dim3 g(grid), b(64 * WM * WN);
-    if constexpr (BK == 16) {
-        if (p.bn_a) {      // launch_igemm has checked: dense destination
-            hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, true, 2, true>), g, b, 0, st, p);
-            return;
-        }
-    }
-    if (pipe == 2) {
-        if (dense)
-            hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, true, 2>), g, b, 0, st, p);
-        else
-            hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, false, 2>), g, b, 0, st, p);
-    } else if (pipe == 1) {
-        if (dense)
-            hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, true, 1>), g, b, 0, st, p);
-        else
-            hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, false, 1>), g, b, 0, st, p);
-    } else {
-        if (dense)
-            hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, true, 0>), g, b, 0, st, p);
-        else
-            hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, false, 0>), g, b, 0, st, p);
-    }
+    if (p.bn_a)      // launch_igemm has checked: dense destination
+        hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, true, true>), g, b, 0, st, p);
+    else if (dense)
+        hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, true>), g, b, 0, st, p);
+    else
+        hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, WN, BK, false>), g, b, 0, st, p);
 }
 
 // Build the fast kernel's arguments; false if the launch does not qualify.
@@ -1616,7 +1517,7 @@ static bool make_fast(const ConvArgs& a, int ntaps, int bk, FastArgs* f) {
     const long long total = (long long)a.src_n * a.H * a.W * a.src_ld - min_off;
     const long long wtotal = (long long)(a.wt_rows) * a.Nout;
     if (total * 4 >= 0x7fffffffLL || wtotal * 4 >= 0x7fffffffLL) return false;
-    p.src = a.src + min_off;
+    p.src = a.src ? a.src + min_off : nullptr;      // (null in the dry runs of the *_tiles queries)
     p.src_bytes = (unsigned)(total * 4);
     p.wt = a.wt;
     p.wt_bytes = (unsigned)(wtotal * 4);
@@ -1725,28 +1626,23 @@ static int launch_igemm(const ConvArgs& a, void* workspace, size_t workspace_byt
         f.sk_chunk1 = pl.chunk1;
         f.sk_slab0 = pl.s0 > 1 ? 0 : f.sk_n0;
         f.tickets = pl.ws_bytes ? (int*)workspace : nullptr;
-        static const int stagger = env_int("Y3_STAGGER", 0);
-        f.stagger = stagger;
         f.slab = pl.ws_bytes ? (float*)((char*)workspace + Y3_WS_HEADER) : nullptr;
         const int grid = f.sk_n0 + (tiles - pl.f) * pl.s1;
         const bool dense = p.dense_dst != 0;
-        if (p.bn_a && (!dense || t.bk != 16)) {
+        if (t.bk != 16) {
+            y3_set_error("conv: the fast kernel is built for K steps of 16 (tile %dx%dx%d)", t.bm, t.bn, t.bk);
+            return Y3_EINVAL;
+        }
+        if (p.bn_a && !dense) {
             y3_set_error("conv: BatchNorm-backward statistics need the dense fast kernel with K steps of 16");
             return Y3_EINVAL;
         }
         switch (key) {
             case 128 * 10000 + 128 * 10 + 0: launch_fast<128, 128, 2, 2, 16>(f, dense, grid, st); break;
-            case 128 * 10000 + 128 * 10 + 1: launch_fast<128, 128, 2, 2, 32>(f, dense, grid, st); break;
             case 128 * 10000 + 64 * 10 + 0: launch_fast<128, 64, 4, 1, 16>(f, dense, grid, st); break;
-            case 128 * 10000 + 64 * 10 + 1: launch_fast<128, 64, 4, 1, 32>(f, dense, grid, st); break;
             case 128 * 10000 + 32 * 10 + 0: launch_fast<128, 32, 4, 1, 16>(f, dense, grid, st); break;
-            case 128 * 10000 + 32 * 10 + 1: launch_fast<128, 32, 4, 1, 32>(f, dense, grid, st); break;
             case 64 * 10000 + 64 * 10 + 0: launch_fast<64, 64, 2, 2, 16>(f, dense, grid, st); break;
-            case 64 * 10000 + 64 * 10 + 1: launch_fast<64, 64, 2, 2, 32>(f, dense, grid, st); break;
             case 64 * 10000 + 128 * 10 + 0: launch_fast<64, 128, 2, 2, 16>(f, dense, grid, st); break;
-            case 64 * 10000 + 128 * 10 + 1: launch_fast<64, 128, 2, 2, 32>(f, dense, grid, st); break;
-            case 256 * 10000 + 128 * 10 + 0: launch_fast<256, 128, 4, 2, 16>(f, dense, grid, st); break;
-            case 256 * 10000 + 128 * 10 + 1: launch_fast<256, 128, 4, 2, 32>(f, dense, grid, st); break;
             default: y3_set_error("conv: no fast kernel for tile %dx%dx%d", t.bm, t.bn, t.bk); return Y3_EINVAL;
         }
         Y3_CHECK_LAUNCH("conv_igemm_fast");
@@ -1890,7 +1786,6 @@ static bool launch_dgrad_multi(const ConvArgs* cls, int ncls, hipStream_t st, in
         m.a[c].sk_slab0 = 0;
         m.a[c].slab = nullptr;
         m.a[c].tickets = nullptr;
-        m.a[c].stagger = 0;
         m.a[c].bn_row0 = rows;
         rows += m.a[c].nbm;
         m.first[c] = first;
@@ -1942,10 +1837,14 @@ extern "C" int y3_conv2d_dgrad_bn_tiles(const y3_tensor* ddst, int ksize, int st
         return rows;
     }
     if (stride != 1) return 0;
+    if (ddst->h != dsrc->h || ddst->w != dsrc->w || ddst->n != dsrc->n) return 0;
     const int taps = ksize * ksize, K = taps * ddst->c, M = dsrc->n * dsrc->h * dsrc->w;
     if (!fast_shape_ok(ddst->c, dsrc->c, K, taps)) return 0;
     const ConvPlan pl = plan_conv(M, dsrc->c, K, true);
     if (pl.t.bk != 16) return 0;
+    // the launch itself must be accepted too (2 GiB buffer limits, tap grid): dry run of the argument builder
+    int ok = 0;
+    if (conv2d_dgrad_impl(ddst, nullptr, ksize, 1, dsrc, 0, nullptr, nullptr, nullptr, 0, nullptr, &ok) != Y3_OK || !ok) return 0;
     return y3_cdiv(M, pl.t.bm);
 }
 
@@ -2007,6 +1906,11 @@ static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize
         p.dense_dst = 1;
         p.K = taps * ddst->c;
         p.M = dsrc->n * p.OH * p.OW;
+        if (dry_rows) {      // would launch_igemm take the fast kernel for this shape?  (pointers are not dereferenced)
+            FastArgs f;
+            *dry_rows = (fast_shape_ok(p.C, p.Nout, p.K, taps) && make_fast(p, taps, 16, &f)) ? 1 : 0;
+            return Y3_OK;
+        }
         if (bn_a) {
             p.bn_a = bn_a->ptr;
             p.bn_a_ld = bn_a->ld;
@@ -2105,7 +2009,7 @@ static WgradPlan plan_wgrad(int K, int Nout, int M, int taps) {
     }
     {
         // experiments: Y3_WGRAD_TILE=bkr,bn (64|128, 32|64|128) for the layers with K <= Y3_WGRAD_TILE_MAXK (default 1024)
-        static const char* ov = getenv("Y3_WGRAD_TILE");
+        static const char* ov = env_str("Y3_WGRAD_TILE");
         static const int maxk = env_int("Y3_WGRAD_TILE_MAXK", 1024);
         int a = 0, b = 0;
         if (ov && K <= maxk && sscanf(ov, "%d,%d", &a, &b) == 2 && (a == 64 || a == 128) && (b == 32 || b == 64 || b == 128) && b <= ((Nout + 31) / 32) * 32) {
@@ -2140,6 +2044,18 @@ static size_t wgrad_ws_bytes(const WgradPlan& w, int K, int Nout) {
     if (w.splits <= 1) return 0;
     if (wgrad_in_kernel(w)) return (size_t)Y3_WS_HEADER + (size_t)w.tiles * w.splits * w.bkr * w.bn * sizeof(float);
     return (size_t)Y3_WS_HEADER + (size_t)w.splits * K * Nout * sizeof(float);
+}
+
+// Diagnostics (include/yolo3hip.h): the plan behind y3_conv2d_wgrad
+extern "C" size_t y3_conv2d_wgrad_plan(int m, int cin, int ksize, int cout, int* out8) {
+    const int taps = ksize * ksize, K = taps * cin;
+    const WgradPlan w = plan_wgrad(K, cout, m, taps);
+    if (out8) {
+        const int v[8] = {w.bkr, w.bn, w.splits, w.chunk, w.tiles, wgrad_in_kernel(w) ? 1 : 0,
+                          (w.splits >= 32 ? y3_cdiv(w.splits, 8) * 8 : w.splits) * w.tiles, Y3_WG_TABLE};
+        for (int i = 0; i < 8; ++i) out8[i] = v[i];
+    }
+    return wgrad_ws_bytes(w, K, cout);
 }
 
 extern "C" size_t y3_conv2d_wgrad_workspace(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride) {

@@ -363,6 +363,315 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128) ? 3 : 1) voi
 }
 
 // ---------------------------------------------------------------------------
+// 256 x 256 x 64 "ping-pong" kernel for the layers that carry the FLOPs of the tiled path (Cin % 64 == 0, Cout >= 256).
+//
+// Why another kernel: conv_bf16_kernel above is bound by operand delivery, not by the matrix pipe (MfmaUtil 14-22 %,
+// DESIGN 3.4): a 128 x 128 tile moves 64 FLOP per operand byte and its loop alternates "everybody loads" / "everybody
+// multiplies".  This one follows the 8-phase recipe of cdna_hip_programming.md 5 (256^2 tile = 128 FLOP / byte, 8 waves,
+// one workgroup per CU, LDS-DMA with a counted vmcnt that never drains in the loop, raw s_barrier, s_setprio around the
+// MFMA clusters) with a schedule laid out for this gather-GEMM:
+//
+//  * waves 2 (M) x 4 (N), each owns 128 x 64 outputs = 2 x 2 quadrants of 64 x 32 = 32 accumulator tiles of
+//    v_mfma_f32_16x16x32_bf16 (128 registers).  A K tile (64 deep) is four PHASES, one quadrant each, 16 MFMAs per phase:
+//        P1 (m0, n0): reads A m0 (8 ds_read_b128) + B n0 (4)      P2 (m0, n1): reads B n1 (4)
+//        P3 (m1, n1): reads A m1 (8)                              P4 (m1, n0): reads nothing (B n0 is still in registers)
+//  * a phase is  [LOAD: the phase's fragment reads, ONE 16 KB staging unit by LDS-DMA, s_waitcnt vmcnt(8)]  s_barrier
+//    [16 MFMAs]  s_barrier.  Waves 4-7 run half a phase behind waves 0-3 (one extra barrier up front): on every SIMD one
+//    wave multiplies while its partner loads, so the matrix pipe sees back-to-back clusters.
+//  * LDS: two K tiles x four units of 128 rows x 128 B: A0 / A1 = the m0 / m1 row blocks of BOTH wave rows, B0 / B1 = the
+//    n0 / n1 column blocks of all four wave columns -- a unit is exactly what ONE phase reads, so it can be refilled (for
+//    the K tile after next) two phases after that phase: P3(t) stages A0(t+2), P4(t) B0(t+2), P1(t+1) B1(t+2), P2(t+1)
+//    A1(t+2).  Every unit is issued 5-6 phases before its first read; vmcnt(8) = "all but the newest four units have
+//    landed" is the only wait, placed one phase before the read with a barrier in between (RAW), and a unit is re-staged
+//    >= 2 phases after its last read (WAR): the two rules of the guide's template, checked here for both wave groups.
+//  * rows are 128 B with the 16-byte quads XOR-swizzled by (row >> 1) & 7 (applied to the SOURCE address of the DMA and to
+//    the fragment reads): conflict-free ds_read_b128 for the 16-row fragments.
+//  * K tiles are processed in pairs (static LDS addresses); an odd count is padded with one all-zero tile (DMA lanes
+//    pointed out of range deposit zeros).
+// Epilogue: as above through LDS in fp32 (two passes of 128 rows), 16-byte residual loads and stores.
+// ---------------------------------------------------------------------------
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+
+#ifdef Y3_TIMING
+__device__ int y3_pp_abl = 0;       // probe only (tools/probe/bf16_pp_probe.hip): 1 no DMA in the loop, 2 no fragment reads, 4 no MFMAs, 8 no vmcnt wait
+#define Y3_PPABL(bit) (y3_pp_abl & (bit))
+#else
+#define Y3_PPABL(bit) 0
+#endif
+#define Y3_PP_UNIT 16384                  // 128 rows x 128 B
+#define Y3_PP_TILE (4 * Y3_PP_UNIT)       // A0 | A1 | B0 | B1
+#define Y3_PP_SLD 260                     // fp32 pitch of the epilogue staging tile
+#define Y3_PP_LDS (128 * Y3_PP_SLD * 4 > 2 * Y3_PP_TILE ? 128 * Y3_PP_SLD * 4 : 2 * Y3_PP_TILE)
+
+__global__ __launch_bounds__(512, 2) void conv_bf16_pp_kernel(const Bf16Args p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Y3_PP_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r16 = lane & 15, lq = lane >> 4;
+    int nbn = p.nbn, ohw = p.ohw, OW = p.OW, aM = p.M, aH = p.H, aW = p.W, src_ld = p.src_ld, csh = p.sh, csw = p.sw, ntaps = p.ntaps;
+    unsigned dn_m = p.dv_nbn.mul, dohw_m = p.dv_ohw.mul, dow_m = p.dv_ow.mul;
+    int dn_s = p.dv_nbn.shift, dohw_s = p.dv_ohw.shift, dow_s = p.dv_ow.shift;
+    Y3_PIN_S(nbn); Y3_PIN_S(ohw); Y3_PIN_S(OW); Y3_PIN_S(aM); Y3_PIN_S(aH); Y3_PIN_S(aW); Y3_PIN_S(src_ld); Y3_PIN_S(csh); Y3_PIN_S(csw); Y3_PIN_S(ntaps);
+    Y3_PIN_S(dn_m); Y3_PIN_S(dohw_m); Y3_PIN_S(dow_m); Y3_PIN_S(dn_s); Y3_PIN_S(dohw_s); Y3_PIN_S(dow_s);
+    const Y3Div dv_nbn = {dn_m, dn_s}, dv_ohw = {dohw_m, dohw_s}, dv_ow = {dow_m, dow_s};
+    const int bid = y3_xcd_remap(blockIdx.x, gridDim.x);
+    const int bm = y3_div(bid, dv_nbn), bn = bid - bm * nbn;
+    const int m0 = bm * 256, n0 = bn * 256;
+
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.wt), 0, p.wt_bytes, 0x00020000);
+
+    // ---- staging addresses.  Unit row R = (i * 8 + wave) * 8 + (lane >> 3), slot = lane & 7 (LDS-DMA: lane l lands at
+    // wave base + 16 l); the lane fetches source quad slot ^ f(R).  A unit s: R < 64 -> tile row s*64 + R of wave row 0,
+    // else 128 + s*64 + (R - 64); B unit s: tile column (R >> 5) * 64 + s * 32 + (R & 31).
+    unsigned a_voff[2][2], a_mask[2][2], b_voff[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int R = (i * 8 + wave) * 8 + (lane >> 3);
+            const int qsrc = (lane & 7) ^ ((R >> 1) & 7);
+            const int m = m0 + (R >> 6) * 128 + s * 64 + (R & 63);
+            const bool ok = m < aM;
+            const int mm = ok ? m : 0;
+            const int n = y3_div(mm, dv_ohw);
+            const int r = mm - n * ohw;
+            const int oh = y3_div(r, dv_ow);
+            const int ow = r - oh * OW;
+            const int ih0 = oh * csh, iw0 = ow * csw;
+            a_voff[s][i] = (unsigned)(((n * aH + ih0) * aW + iw0) * src_ld + qsrc * 8) * 2u;
+            unsigned msk = 0;
+            for (int t = 0; t < ntaps; ++t) {
+                const int ih = ih0 + p.tap_dh[t], iw = iw0 + p.tap_dw[t];
+                if (ok && (unsigned)ih < (unsigned)aH && (unsigned)iw < (unsigned)aW) msk |= 1u << t;
+            }
+            a_mask[s][i] = msk;
+            const int nn = n0 + (R >> 5) * 64 + s * 32 + (R & 31);
+            b_voff[s][i] = nn < p.Nout ? (unsigned)(nn * p.C + qsrc * 8) * 2u : Y3_OOB;
+        }
+
+    struct Ktile {      // scalars of one K tile (wave-uniform)
+        unsigned a_soff, b_soff;
+        int tap, valid;
+    };
+    const int nk = p.K >> 6;
+    auto ktile = [&](int t) {
+        Ktile k;
+        const int k0 = min(t, nk - 1) << 6;
+        k.tap = k0 >> p.logC;
+        const int cb = k0 & p.cmask;
+        const int ty = p.tg_nx == 1 ? k.tap : (k.tap * 11) >> 5;      // tap / 3 for tap < 9
+        const int tx = k.tap - ty * p.tg_nx;
+        k.a_soff = (unsigned)(p.tap_off0 + ty * p.tg_offy + tx * p.tg_offx + cb * 2);
+        k.b_soff = (unsigned)(k.tap * p.tap_wt1 + cb) * 2u;
+        k.valid = t < nk;
+        return k;
+    };
+    // unit u of buffer b: 0 = A0, 1 = A1, 2 = B0, 3 = B1
+    auto stage_a = [&](int buf, int s, const Ktile& k) {
+        if (Y3_PPABL(1)) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned char* dst = smem + buf * Y3_PP_TILE + s * Y3_PP_UNIT + (i * 8 + wave) * 1024;
+            Y3_GLDS16(rs_src, dst, (k.valid && ((a_mask[s][i] >> k.tap) & 1u)) ? a_voff[s][i] : Y3_OOB, k.a_soff);
+        }
+    };
+    auto stage_b = [&](int buf, int s, const Ktile& k) {
+        if (Y3_PPABL(1)) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned char* dst = smem + buf * Y3_PP_TILE + (2 + s) * Y3_PP_UNIT + (i * 8 + wave) * 1024;
+            Y3_GLDS16(rs_wt, dst, k.valid ? b_voff[s][i] : Y3_OOB, k.b_soff);
+        }
+    };
+
+    // ---- fragment addresses: 16 rows x (4 quads of one 32-deep K step); lane: row r16, quad lq
+    const int swz = (r16 >> 1) & 7;
+    const int qo0 = ((lq) ^ swz) * 16, qo1 = ((4 + lq) ^ swz) * 16;
+    const unsigned char* a_lane = smem + (wr * 64 + r16) * 128;
+    const unsigned char* b_lane = smem + (wc * 32 + r16) * 128;
+    bf16x8 af[4][2], bfr[2][2][2];      // A: [row tile][k step]; B: [n sub][col tile][k step]
+    f32x4t acc[2][4][2][2];             // [m sub][row tile][n sub][col tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4t{0.f, 0.f, 0.f, 0.f};
+
+    auto read_a = [&](int buf, int s) {
+        if (Y3_PPABL(2)) return;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const unsigned char* q = a_lane + buf * Y3_PP_TILE + s * Y3_PP_UNIT + rt * 2048;
+            af[rt][0] = *reinterpret_cast<const bf16x8*>(q + qo0);
+            af[rt][1] = *reinterpret_cast<const bf16x8*>(q + qo1);
+        }
+    };
+    auto read_b = [&](int buf, int s) {
+        if (Y3_PPABL(2)) return;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const unsigned char* q = b_lane + buf * Y3_PP_TILE + (2 + s) * Y3_PP_UNIT + ct * 2048;
+            bfr[s][ct][0] = *reinterpret_cast<const bf16x8*>(q + qo0);
+            bfr[s][ct][1] = *reinterpret_cast<const bf16x8*>(q + qo1);
+        }
+    };
+    auto mma = [&](auto SM, auto SN) {
+        constexpr int sm = decltype(SM)::value, sn = decltype(SN)::value;
+        if (Y3_PPABL(4)) return;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    acc[sm][rt][sn][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rt][ks], bfr[sn][ct][ks], acc[sm][rt][sn][ct], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto load_end = [&]() {       // end of a LOAD section: all but the newest four units have landed; the group barrier
+        if (!Y3_PPABL(8)) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma_end = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    // one K tile in buffer BUF; k1 = scalars of tile t + 1, k2 = of tile t + 2 (computed in P3)
+    auto tile = [&](auto BUF, int t, Ktile& k1, Ktile& k2) {
+        constexpr int buf = decltype(BUF)::value;
+        // P1 (m0, n0)
+        read_b(buf, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(buf, 0);
+        stage_b(buf ^ 1, 1, k1);
+        load_end();
+        mma(I0{}, I0{});
+        mma_end();
+        // P2 (m0, n1)
+        read_b(buf, 1);
+        stage_a(buf ^ 1, 1, k1);
+        load_end();
+        mma(I0{}, I1{});
+        mma_end();
+        // P3 (m1, n1)
+        read_a(buf, 1);
+        k2 = ktile(t + 2);
+        stage_a(buf, 0, k2);
+        load_end();
+        mma(I1{}, I1{});
+        mma_end();
+        // P4 (m1, n0)
+        stage_b(buf, 0, k2);
+        load_end();
+        mma(I1{}, I0{});
+        mma_end();
+        k1 = k2;
+    };
+
+    Y3_TSTAMP(0);
+    // ---- prologue: tile 0 complete, A0 / B0 of tile 1 (the loop issues B1(1) in P1(0), A1(1) in P2(0), ...)
+    Ktile k0 = ktile(0), k1 = ktile(1), k2 = k1;
+    stage_a(0, 0, k0);
+    stage_b(0, 0, k0);
+    stage_b(0, 1, k0);
+    stage_a(0, 1, k0);
+    stage_a(1, 0, k1);
+    stage_b(1, 0, k1);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 8);      // A0(0), B0(0) have landed (this wave's share)
+    __builtin_amdgcn_s_barrier();                // ... everybody's
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run half a phase behind
+    Y3_TSTAMP(1);
+    const int npairs = (nk + 1) >> 1;
+    for (int it = 0; it < npairs; ++it) {
+        tile(I0{}, 2 * it, k1, k2);
+        tile(I1{}, 2 * it + 1, k1, k2);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // barrier counts of the two groups match again
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): no DMA may land in the block the epilogue re-uses
+    __syncthreads();
+    Y3_TSTAMP(2);
+
+    // ---- epilogue.  D layout of 16x16 tiles: column = lane & 15 (channel), row = 4 * (lane >> 4) + reg.
+    float* stage = reinterpret_cast<float*>(smem);
+    const bool do_lrelu = p.flags & Y3_EPI_LRELU;
+    const bool has_scale = p.scale != nullptr, has_resid = p.resid != nullptr;
+    float bias[2][2], sc[2][2], sf[2][2];
+#pragma unroll
+    for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int n = n0 + wc * 64 + sn * 32 + ct * 16 + r16;
+            const bool nok = n < p.Nout;
+            bias[sn][ct] = (p.bias && nok) ? p.bias[n] : 0.f;
+            sc[sn][ct] = (has_scale && nok) ? p.scale[n] : 1.f;
+            sf[sn][ct] = (has_scale && nok) ? p.shift[n] : 0.f;
+        }
+    const char* resid_b = reinterpret_cast<const char*>(p.resid);
+    char* dst_b = reinterpret_cast<char*>(p.dst);
+#pragma unroll
+    for (int sm = 0; sm < 2; ++sm) {
+        // staged row = wr * 64 + rt * 16 + 4 * lq + reg  <->  tile row wr * 128 + sm * 64 + (staged row & 63)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[sm][rt][sn][ct][r] + bias[sn][ct];
+                        if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
+                        if (has_scale) v = v * sc[sn][ct] + sf[sn][ct];
+                        stage[(wr * 64 + rt * 16 + 4 * lq + r) * Y3_PP_SLD + wc * 64 + sn * 32 + ct * 16 + r16] = v;
+                    }
+        __syncthreads();
+#pragma unroll 2
+        for (int idx = tid; idx < 128 * 32; idx += 512) {
+            const int row = idx >> 5, c8 = (idx & 31) * 8;
+            const int m = m0 + (row >> 6) * 128 + sm * 64 + (row & 63), n = n0 + c8;
+            if (m >= p.M || n >= p.Nout) continue;
+            const float* sp = stage + row * Y3_PP_SLD + c8;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(sp), hi = *reinterpret_cast<const f32x4*>(sp + 4);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (has_resid) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(resid_b + ((size_t)m * p.resid_ld + n) * 2);
+                const unsigned rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += __uint_as_float(rw[e] << 16);
+                    v[2 * e + 1] += __uint_as_float(rw[e] & 0xffff0000u);
+                }
+            }
+            if (p.out_f32) {
+                float* d = reinterpret_cast<float*>(dst_b + ((size_t)m * p.dst_ld + n) * 4);
+                *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+                unsigned pk[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (unsigned)f32_to_bf16(v[2 * e]) | ((unsigned)f32_to_bf16(v[2 * e + 1]) << 16);
+                *reinterpret_cast<uint4*>(dst_b + ((size_t)m * p.dst_ld + n) * 2) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
+        }
+        if (sm == 0) __syncthreads();
+    }
+#ifdef Y3_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    Y3_TSTAMP(3);
+}
+
+// ---------------------------------------------------------------------------
 // The RGB layer (3x3, stride 1, Cin padded to 4, Cout = 32): K = 36 is far too short for the matrix pipe and the
 // layer is a pure write stream (32 channels out for 4 in), so it is a direct convolution on the vector ALU.  A thread
 // owns 4 consecutive pixels of a row x 8 channels: per input row it loads the 6 float4 pixels its 4 windows cover, and
@@ -603,6 +912,19 @@ extern "C" int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, c
     static const int force = getenv("Y3_BF16_TILE") ? atoi(getenv("Y3_BF16_TILE")) : 0;   // experiments: 1 = 64x64, 2 = 128x128, 3 = 256x128
     const long long t256 = (long long)y3_cdiv(p.M, 256) * y3_cdiv(p.Nout, 128);
     const long long t128 = (long long)y3_cdiv(p.M, 128) * y3_cdiv(p.Nout, 128);
+    // the 256 x 256 ping-pong kernel: whole 64-deep K tiles inside one tap, 16-byte rows for the epilogue, Cout in eights
+    static const int pp_mode = getenv("Y3_BF16_PP") ? atoi(getenv("Y3_BF16_PP")) : 1;     // 0 = off (A/B against conv_bf16_kernel)
+    const long long tpp = (long long)y3_cdiv(p.M, 256) * y3_cdiv(p.Nout, 256);
+    if (pp_mode && p.C % 64 == 0 && p.Nout >= 256 && p.Nout % 8 == 0 && p.vec_ok && tpp >= (pp_mode == 2 ? 1 : 96)) {
+        p.nbn = y3_cdiv(p.Nout, 256);
+        p.ohw = p.OH * p.OW;
+        p.dv_nbn = y3_make_div(p.nbn);
+        p.dv_ohw = y3_make_div(p.ohw);
+        p.dv_ow = y3_make_div(p.OW);
+        hipLaunchKernelGGL(conv_bf16_pp_kernel, dim3((unsigned)tpp), dim3(512), 0, st, p);
+        Y3_CHECK_LAUNCH("conv_bf16_pp");
+        return Y3_OK;
+    }
     if (p.Nout <= 32) {
         p.nbn = 1;
         launch_bf16<128, 32, 4, 1>(p, y3_cdiv(p.M, 128), st);

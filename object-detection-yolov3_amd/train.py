@@ -46,6 +46,17 @@ def abort_on_nan(loss_value, message):
         raise RuntimeError(message)
 
 
+def effective_reader_count(requested, cpus, local_world):
+    """Reader processes per GPU.  The reference starts READER_COUNT = 3 per GPU (train.py:16) for a TensorFlow step; a ~17 ms
+    step with augmentation on (~20 ms of CPU per image) wants about 12 (tools/train_throughput.py).  Two readers (train, test)
+    run per rank and every rank of the node shares the host, so both the default and an explicit --reader_count are capped by
+    the cores one rank may use: cpus // local_world minus one for the rank's own main + prefetch threads, never below 1."""
+    share = max(1, (cpus or 1) // max(local_world, 1) - 1)
+    if requested is None:
+        requested = max(READER_COUNT, min(12, share - 1))
+    return max(1, min(int(requested), share))
+
+
 def train_model(batch_size, test_every_n_steps, train_database_filepath, test_database_filepath, output_folder, early_stopping_count,
                 learning_rate, use_augmentation, max_epochs=None, reader_count=None, backend='nccl'):
     os.makedirs(output_folder, exist_ok=True)
@@ -55,11 +66,11 @@ def train_model(batch_size, test_every_n_steps, train_database_filepath, test_da
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     global_batch_size = batch_size * world
-    if reader_count is None:
-        # the reference's 3 readers per GPU feed a TensorFlow step; a 24 ms step with augmentation on (~20 ms of CPU per image)
-        # needs about 8 -- measured with tools/train_throughput.py: 4 readers 192 images/s, 12 readers 337 (GPU bound)
-        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
-        reader_count = max(READER_COUNT, min(12, (os.cpu_count() or 8) // max(local_world, 1) - 2))
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
+    asked = reader_count
+    reader_count = effective_reader_count(reader_count, os.cpu_count() or 8, local_world)
+    if asked is not None and reader_count != asked:
+        print('reader_count {} capped to {} ({} cpus / {} ranks on this node)'.format(asked, reader_count, os.cpu_count(), local_world))
 
     # readers first: their worker processes are forked before this process touches the GPU
     from yolo3 import imagereader
@@ -83,6 +94,8 @@ def train_model(batch_size, test_every_n_steps, train_database_filepath, test_da
         import torch.distributed as dist
         from yolo3 import model
         torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        from yolo3 import streams
+        streams.reserve()      # side / comm streams bind to hardware queues before a communicator creates its own (yolo3/streams.py)
         strategy = None
         if world > 1:
             os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')

@@ -86,6 +86,9 @@ SIGNATURES = {
     'y3_comm_unique_id': (i32, [vp]),
     'y3_comm_init': (i32, [vp, i32, i32, C.POINTER(C.c_void_p)]),
     'y3_allreduce_sum_f32': (i32, [vp, fp, sz, vp]),
+    'y3_conv2d_plan': (sz, [i32, i32, i32, i32, C.POINTER(C.c_int)]),
+    'y3_conv2d_wgrad_plan': (sz, [i32, i32, i32, i32, C.POINTER(C.c_int)]),
+    'y3_comm_info': (i32, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'y3_comm_destroy': (i32, [vp]),
     'y3_zscore': (i32, [fp, fp, i32, sz, vp, vp]),
     'y3_zscore_workspace_bytes': (sz, [i32]),

@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from . import _hip
+from . import streams
 from ._hip import lib, check, view, EPI_LRELU, EPI_ACCUM
 
 BN_EPS = 1e-3          # Keras BatchNormalization defaults
@@ -467,7 +468,7 @@ class _Plan:
         # the two branches gained nothing -- 23.8 ms -- so a graph-captured step keeps one stream.)  dz is double-buffered:
         # bn_bwd_apply of layer i-2 waits for the kernel gradient of layer i that still reads the buffer.
         two = (not mdl.use_graph) and os.environ.get('Y3_WGRAD_STREAM', '1') != '0'
-        self.side = torch.cuda.Stream(device=mdl.device) if two else None
+        self.side = streams.reserve(mdl.device)[0] if two else None      # one per device, bound to its hardware queue early (streams.py)
         self.events = []
         dz_bufs = [self.dz, torch.empty_like(self.dz)] if two else [self.dz]
         dz_busy = [None, None]          # event index of the wgrad still reading each dz buffer

@@ -6,9 +6,13 @@ import glob
 import json
 import os
 
+import sys
+
 import numpy as np
 import pytest
 import torch
+
+from oracle import model as om
 
 
 def test_oracle_nms_matches_reference_goldens(golden_dir):
@@ -155,3 +159,124 @@ def test_oracle_adam_is_keras_form():
     lr_t = 0.1 * np.sqrt(1 - 0.999) / (1 - 0.9)
     want = np.array([1.0, -2.0]) - lr_t * (0.1 * g.numpy()) / (np.sqrt(0.001 * g.numpy() ** 2) + 1e-7)
     np.testing.assert_allclose(p.numpy(), want, rtol=1e-12)
+
+
+# ---- the reference's own model.py text, executed over a recording / NumPy stand-in of TensorFlow (tests/golden/make_golden_model.py) ----
+# TensorFlow is absent, so these do not pin TF arithmetic (parity for A1-A16 stays "unpinned"); they pin the TRANSCRIPTION:
+# layer order and attributes, the residual / concat wiring, and the decode / loss formulas as model.py writes them.
+def _arch(golden_dir, tag):
+    import json
+    with open(os.path.join(golden_dir, 'arch.json')) as fh:
+        return json.load(fh)[tag]
+
+
+@pytest.mark.parametrize('tag,cin,A,K', [('rgb416_a2_k2', 3, 2, 2), ('gray96x160_a3_k3', 1, 3, 3)])
+def test_layer_tables_equal_the_graph_the_reference_builds(golden_dir, tag, cin, A, K):
+    """oracle.layer_specs and the product's build_layer_specs against the Keras layer calls model.py:356-421,423-464 makes."""
+    arch = _arch(golden_dir, tag)
+    g = arch['graph']
+    convs = [n for n in g if n['kind'] == 'Conv2D']
+    by_out = {n['out']: n for n in g}
+    consumers = {}
+    for n in g:
+        for i in n['inputs']:
+            consumers.setdefault(i, []).append(n)
+    want = []
+    for c in convs:
+        nxt = consumers.get(c['out'], [])
+        bn = len(nxt) == 1 and nxt[0]['kind'] == 'BatchNormalization'
+        assert c['padding'] == 'same' and c['data_format'] == 'channels_first' and c['use_bias'] and c['l2'] == 0.0005      # Q9: declared, never applied
+        assert (c['activation'] == 'leaky_relu') == bn            # Q1: conv -> leaky_relu -> BN; the heads are linear and have no BN
+        if bn:
+            assert nxt[0]['axis'] == 1
+        want.append(dict(cin=c['cin'], cout=c['filters'], k=c['kernel'], s=c['stride'], bn=bn))
+    assert om.layer_specs(cin, A, K) == want
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'object-detection-yolov3_amd'))
+    from yolo3.model import build_layer_specs
+    specs = build_layer_specs(cin, A, K)[0]
+    assert [dict(cin=s.cin, cout=s.cout, k=s.k, s=s.s, bn=bool(s.bn)) for s in specs] == want
+    # names and outputs (model.py:111-118, 462-463), frozen all-ones transposed convs (Q3), anchors default (model.py:433)
+    assert [c['name'] for c in convs if c['name']] == ['feature_map_1', 'feature_map_2', 'feature_map_3']
+    fm_model = [m for m in arch['models'] if m['name'] == 'yolov3_fm'][0]
+    assert [by_out[o]['name'] for o in fm_model['outputs']] == ['feature_map_1', 'feature_map_2', 'feature_map_3']
+    ups = [n for n in g if n['kind'] == 'Conv2DTranspose']
+    assert len(ups) == 2 and all(u['kernel'] == 2 and u['stride'] == 2 and u['kernel_initializer'] == 'ones' and not u['trainable']
+                                 and u['filters'] == u['cin'] for u in ups)
+    assert sum(n['kind'] == 'add' for n in g) == 23 and sum(n['kind'] == 'concat' for n in g) == 2
+    if tag.startswith('gray'):
+        assert arch['anchors'] == [[32, 32], [128, 128], [256, 256]]
+    assert arch['optimizer'] == {'optimizer': 'Adam', 'learning_rate': 1e-4}
+    assert arch['constants']['BLOCK_COUNT'] == 8 and arch['constants']['FILTER_COUNT'] == 1024
+
+
+def test_oracle_forward_equals_an_interpreter_of_the_recorded_graph(golden_dir):
+    """Wiring: the recorded graph (every Keras call + tf.add / tf.concat with operand ids, as model.py issues them) is
+    interpreted node by node with plain torch ops and must reproduce oracle.Net.feature_maps on the same weights --
+    residual adds take the BLOCK input (Q2), the lateral 1x1 convs keep their channel count (Q4), concat order
+    [upsampled, route] (model.py:368,375)."""
+    import torch.nn.functional as F
+    arch = _arch(golden_dir, 'rgb416_a2_k2')
+    A, K = 2, 2
+    params = om.init_params(3, A, K, seed=4, randomize_bn=True)
+    net = om.Net(params, 3, A, K, dtype=torch.float64)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 64, 96, generator=g, dtype=torch.float64)
+    want = net.feature_maps(x, training=False)
+    val, ci = {}, [0]
+    last_conv = {}
+    for n in arch['graph']:
+        ins = [val[i] for i in n['inputs']]
+        if n['kind'] == 'Input':
+            v = x
+        elif n['kind'] == 'Conv2D':
+            q = net.p[ci[0]]
+            last_conv[n['out']] = ci[0]
+            ci[0] += 1
+            t = ins[0]
+            ph, pw = om.same_pad(t.shape[2], n['kernel'], n['stride']), om.same_pad(t.shape[3], n['kernel'], n['stride'])
+            v = F.conv2d(F.pad(t, (pw[0], pw[1], ph[0], ph[1])), q['W'].permute(3, 2, 0, 1), q['b'], stride=n['stride'])
+            if n['activation'] == 'leaky_relu':
+                v = F.leaky_relu(v, 0.2)
+        elif n['kind'] == 'BatchNormalization':
+            q = net.p[last_conv[n['inputs'][0]]]
+            sh = (1, -1, 1, 1)
+            v = (ins[0] - q['mean'].view(sh)) / torch.sqrt(q['var'].view(sh) + 1e-3) * q['gamma'].view(sh) + q['beta'].view(sh)
+        elif n['kind'] == 'add':
+            v = ins[0] + ins[1]
+        elif n['kind'] == 'concat':
+            v = torch.cat(ins, dim=n['axis'])
+        elif n['kind'] == 'Conv2DTranspose':
+            c = ins[0].shape[1]
+            v = F.conv_transpose2d(ins[0], torch.ones(c, n['filters'], 2, 2, dtype=ins[0].dtype), stride=2)
+        val[n['out']] = v
+    outs = [m for m in arch['models'] if m['name'] == 'yolov3_fm'][0]['outputs']
+    for o, w in zip(outs, want):
+        assert val[o].shape == w.shape
+        assert float((val[o] - w).abs().max()) <= 1e-9 * float(w.abs().max())
+
+
+@pytest.mark.parametrize('tag', ['sq', 'rect'])
+def test_decode_and_loss_equal_the_reference_text_over_numpy(golden_dir, tag):
+    """oracle.reorg_layer / decode / loss_layer / compute_loss against model.py:122-354 executed as written over NumPy float32
+    stand-ins of the tf.* calls: square 416 input with 2 anchors (stride quirk Q6 invisible) and a 96 x 160 input with 3
+    anchors (Q6 visible: stride (s_y, s_x) multiplies (x, y)); V = 0 (no ground-truth box at a scale) and V > 0."""
+    z = np.load(os.path.join(golden_dir, 'model_fwd.npz'))
+    H, W, C, K, N = (int(v) for v in z[tag + '_meta'])
+    anchors = [tuple(float(v) for v in a) for a in z[tag + '_anchors']]
+    fms = [torch.from_numpy(z['%s_fm%d' % (tag, i)]) for i in range(3)]
+    gts = [torch.from_numpy(z['%s_gt%d' % (tag, i)]) for i in range(3)]
+    rows = om.decode(fms, (H, W, C), anchors, K).numpy()
+    ref = z[tag + '_rows']
+    assert rows.shape == ref.shape
+    np.testing.assert_allclose(rows, ref, rtol=2e-6, atol=2e-6 * np.abs(ref).max())
+    for i in range(3):
+        xy_off, boxes, _, _ = om.reorg_layer(fms[i], (H, W, C), anchors, K)
+        assert np.array_equal(xy_off.numpy(), z['%s_reorg%d_xy_offset' % (tag, i)])
+        np.testing.assert_allclose(boxes.numpy(), z['%s_reorg%d_boxes' % (tag, i)], rtol=2e-6, atol=1e-5)
+        for suffix, gt in (('', gts[i]), ('_v0', torch.zeros_like(gts[i]))):
+            for dt, tol in ((torch.float32, 2e-5), (torch.float64, 2e-5)):
+                got = [float(v) for v in om.loss_layer(fms[i].to(dt), gt.to(dt), (H, W, C), anchors, K)]
+                np.testing.assert_allclose(got, z['%s_loss%d%s' % (tag, i, suffix)], rtol=tol, atol=1e-6)
+    tot = [float(v) for v in om.compute_loss([f.double() for f in fms], [g.double() for g in gts], (H, W, C), anchors, K)]
+    np.testing.assert_allclose(tot, z[tag + '_compute_loss'], rtol=2e-5)
+    assert float(z[tag + '_loss0'][0]) > 0 and float(z[tag + '_loss0_v0'][0]) == 0.0      # V > 0 really has boxes; V = 0 has none

@@ -43,3 +43,17 @@ def test_nan_abort():
         train.abort_on_nan(float('nan'), 'Training Loss went to NaN, try a lower learning rate')
     with pytest.raises(RuntimeError, match='Test Loss went to NaN'):
         train.abort_on_nan(np.float32('nan'), 'Test Loss went to NaN')
+
+
+def test_reader_count_is_capped_by_the_cores_one_rank_may_use():
+    """VERDICT r2 #1(d): 8 ranks x 12 readers x 2 readers-per-rank on one host CPU must not happen by default or by flag."""
+    from train import effective_reader_count, READER_COUNT
+    assert effective_reader_count(None, 128, 1) == 12                 # one GPU, big host: the measured sweet spot
+    assert effective_reader_count(None, 128, 8) == 12                 # 16 cores per rank
+    assert effective_reader_count(None, 64, 8) == 6                   # 8 cores per rank: 7 usable, default share - 1
+    assert effective_reader_count(None, 16, 8) == 1                   # 2 cores per rank
+    assert effective_reader_count(None, 8, 1) == 6                    # this container
+    assert effective_reader_count(3, 128, 8) == 3                     # the reference's value passes through
+    assert effective_reader_count(48, 128, 8) == 15                   # an explicit request is capped too
+    assert effective_reader_count(12, 8, 8) == 1 and effective_reader_count(0, 8, 1) == 1
+    assert READER_COUNT == 3

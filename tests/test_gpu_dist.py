@@ -108,6 +108,49 @@ def test_two_rank_step_sums_gradients_and_matches_oracle(tmp_path):
         assert err <= 6.0 * noise + 5e-3, 'summed gradient tensor %d: rel L2 err %.3e (oracle fp32 noise %.3e)' % (i, err, noise)
 
 
+def _run_one_rank(out_dir, img, n, seed, wgrad_stream, backend, transport):
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+               Y3_WGRAD_STREAM=wgrad_stream, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    log = os.path.join(out_dir, 'rank0.log')
+    with open(log, 'w') as fh:
+        rc = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'), out_dir, str(img), str(n), str(seed), backend, transport],
+                            env=env, stdout=fh, stderr=subprocess.STDOUT, timeout=900).returncode
+    assert rc == 0, open(log).read()[-4000:]
+    return np.load(os.path.join(out_dir, 'rank0.npz'))
+
+
+@pytest.mark.parametrize('transport', ['torch', 'native'])
+def test_rccl_backend_one_rank_forced_collectives_equal_plain_step(tmp_path, transport):
+    """The REAL transport on the one GPU this box has: torch.distributed backend ``nccl`` (= RCCL) with a one-rank
+    communicator and DataParallel(force_collective=True), so that every gradient bucket is all-reduced although the sum
+    over one rank is the identity.  What this exercises and the gloo tests cannot: RCCL's own stream, Work.wait() as a
+    STREAM wait (gloo's blocks the host and so hides any missing stream dependency), and the side-stream -> compute stream
+    -> comm stream -> compute stream event chain of _Plan._run / DataParallel.  Three consecutive steps; gradients, weights,
+    Adam moments and BatchNorm moving statistics must equal three plain (no process group) steps BIT FOR BIT, with the
+    kernel gradients on the second stream (Y3_WGRAD_STREAM=1) and on the compute stream (=0).  ``native``: the same through
+    y3_comm_* (RCCL called directly on DataParallel's comm stream)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from dp_worker import make_case
+    from yolo3.model import YoloV3
+    img, n, seed = 96, 4, 13
+    anchors, K, params, images, gts = make_case(img, n, seed)
+    m = YoloV3(n, [img, img, 3], K, anchors, learning_rate=1e-3)
+    m.set_weights(params)
+    for _ in range(3):
+        loss = float(m.train_step((images.cuda(), [torch.from_numpy(x).cuda() for x in gts])))
+    torch.cuda.synchronize()
+    want = dict(grads=m.grads.cpu().numpy(), params=m.params.cpu().numpy(), moving=m.moving.cpu().numpy(), adam_m=m.adam_m.cpu().numpy())
+    for ws in ('1', '0'):
+        d = tmp_path / ('ws' + ws)
+        d.mkdir()
+        z = _run_one_rank(str(d), img, n, seed, ws, 'nccl', transport)
+        assert int(z['buckets']) >= 2 and int(z['collectives']) == int(z['buckets'])      # every bucket really was all-reduced
+        assert int(z['communicator_ranks']) == 1
+        for k, v in want.items():
+            assert np.array_equal(z[k], v), 'wgrad stream %s, %s transport: %s differs from the plain step' % (ws, transport, k)
+        assert abs(float(z['loss']) - loss) <= 1e-6 * abs(loss)
+
+
 def test_bench_self_launches_two_ranks():
     """`python bench.py --gpus 2` (no launcher) spawns its own ranks and prints one JSON line (VERDICT r1 missing #1)."""
     import json
@@ -118,6 +161,9 @@ def test_bench_self_launches_two_ranks():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 16 and out['replicas_identical'] is True
+    comm = out['comm']          # what the communicator saw and how much of the all-reduce the compute stream waited for
+    assert comm['backend'] == 'gloo' and comm['world_size'] == 2 and comm['communicator_ranks'] == 2 and comm['buckets'] >= 2
+    assert comm['allreduce_ms_sum'] > 0 and comm['allreduce_ms_exposed'] >= 0
     assert np.isfinite(out['final_loss']) and out['value'] > 0 and out['scaling'] == 'weak'
 
 

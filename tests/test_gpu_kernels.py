@@ -123,6 +123,13 @@ BF16_CASES = [
     (3, 20, 20, 64, 64, 3, 1, True, False),      # BN=64 tile, ragged M
     (1, 13, 13, 512, 1024, 3, 1, True, False),   # long K
     (1, 26, 26, 768, 256, 1, 1, False, False),   # 1x1 with non-power-of-two Cin (route concat)
+    # the 256 x 256 ping-pong kernel (conv_bf16_pp_kernel: Cin % 64 == 0, Cout >= 256, >= 96 tiles)
+    (1, 78, 79, 64, 1024, 1, 1, False, False),   # ONE K tile (+ the all-zero pad tile), ragged M (6162 rows)
+    (1, 80, 80, 64, 1024, 3, 1, True, False),    # 3x3 zero padding through the DMA masks, 9 K tiles (odd), residual
+    (2, 80, 80, 64, 320, 1, 1, False, True),     # Cout 320: second column tile a quarter full, fp32 out
+    (1, 160, 160, 64, 1024, 3, 2, False, False), # stride 2 (asymmetric SAME padding)
+    (1, 80, 80, 128, 1024, 1, 1, True, False),   # 2 K tiles, residual
+    (1, 78, 80, 192, 1024, 1, 1, False, False),  # non-power-of-two Cin (1x1), 3 K tiles
 ]
 
 
@@ -608,6 +615,54 @@ def test_loss_fwd_bwd_matches_oracle(hip, empty):
                                           A, K, img, img, gbs, loss4.data_ptr(), hip.Tensor(dv.data_ptr(), n, G, G, 14, 16), ws.data_ptr(), stream()))
         assert_close(dv.cpu().permute(0, 3, 1, 2), fm.grad, rtol=1e-4, what='dfm scale %d' % s)
     assert_close(loss4.cpu(), ref_parts, rtol=2e-5, what='loss parts (xy, wh, obj, class)')
+
+
+@pytest.mark.parametrize('tag', ['sq', 'rect'])
+def test_decode_and_loss_match_reference_text_fixtures(hip, golden_dir, tag):
+    """y3_decode_fwd and y3_loss_fwd_bwd against tests/golden/model_fwd.npz: the reference's own reorg_layer /
+    convert_feature_map_to_inference_detections / loss_layer text (model.py:122-354) executed over NumPy float32 stand-ins of
+    the tf.* calls (make_golden_model.py; TensorFlow itself is absent, so this pins the transcription, not TF arithmetic).
+    Square 416 input with 2 anchors and a 96 x 160 input with 3 anchors / 3 classes (stride quirk Q6 visible), V > 0 and
+    V = 0.  Rows 1e-5 of the box scale, losses 1e-4."""
+    from util import nhwc_buf, stream, assert_close
+    z = np.load(os.path.join(golden_dir, 'model_fwd.npz'))
+    H, W, C, K, n = (int(v) for v in z[tag + '_meta'])
+    anchors = [tuple(float(v) for v in a) for a in z[tag + '_anchors']]
+    A = len(anchors)
+    D = A * (5 + K)
+    ld = (D + 3) // 4 * 4
+    anc = hip.float_array([v for a in anchors for v in a])
+    arr = (hip.Tensor * 3)()
+    views = []
+    for i in range(3):
+        f = torch.from_numpy(z['%s_fm%d' % (tag, i)])
+        _, v = nhwc_buf(n, f.shape[2], f.shape[3], D, ld=ld, fill=0.0)
+        v.copy_(f.permute(0, 2, 3, 1))
+        views.append(v)
+        arr[i] = hip.Tensor(v.data_ptr(), n, f.shape[2], f.shape[3], D, ld)
+    ref = z[tag + '_rows']
+    out = torch.empty(n, ref.shape[1], 5 + K, device='cuda')
+    hip.check(hip.lib.y3_decode_fwd(arr, 3, anc, A, K, H, W, out.data_ptr(), stream()))
+    assert_close(out.cpu()[..., :4], ref[..., :4], rtol=1e-5, what='boxes')
+    assert_close(out.cpu()[..., 4:], ref[..., 4:], rtol=1e-5, atol=2e-6, what='scores')
+    ws = torch.zeros(int(hip.lib.y3_loss_workspace_bytes()) // 4 + 4, device='cuda')
+    for suffix in ('', '_v0'):
+        loss4 = torch.zeros(4, device='cuda')
+        want = np.zeros(4)
+        for i in range(3):
+            gt = torch.from_numpy(z['%s_gt%d' % (tag, i)])
+            if suffix:
+                gt = torch.zeros_like(gt)
+            want += z['%s_loss%d%s' % (tag, i, suffix)]
+            gh, gw = gt.shape[1], gt.shape[2]
+            _, dv = nhwc_buf(n, gh, gw, D, ld=ld, fill=0.0)
+            gd = gt.float().cuda().contiguous()
+            hip.check(hip.lib.y3_loss_fwd_bwd(hip.Tensor(views[i].data_ptr(), n, gh, gw, D, ld), gd.data_ptr(), anc, A, K, H, W, float(n),
+                                              loss4.data_ptr(), hip.Tensor(dv.data_ptr(), n, gh, gw, D, ld), ws.data_ptr(), stream()))
+            assert bool(torch.isfinite(dv).all())
+        assert_close(loss4.cpu(), want, rtol=1e-4, what='loss parts (xy, wh, obj, class)%s' % suffix)
+        if not suffix:
+            assert_close(float(loss4.sum()), float(z[tag + '_compute_loss'][0]), rtol=1e-4, what='compute_loss total')
 
 
 def test_adam_matches_oracle(hip):
