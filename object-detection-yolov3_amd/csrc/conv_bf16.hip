@@ -368,47 +368,66 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128) ? 3 : 1) voi
 // Why another kernel: conv_bf16_kernel above is bound by operand delivery, not by the matrix pipe (MfmaUtil 14-22 %,
 // DESIGN 3.4): a 128 x 128 tile moves 64 FLOP per operand byte and its loop alternates "everybody loads" / "everybody
 // multiplies".  This one follows the 8-phase recipe of cdna_hip_programming.md 5 (256^2 tile = 128 FLOP / byte, 8 waves,
-// one workgroup per CU, LDS-DMA with a counted vmcnt that never drains in the loop, raw s_barrier, s_setprio around the
-// MFMA clusters) with a schedule laid out for this gather-GEMM:
+// one workgroup per CU, LDS-DMA with a counted vmcnt that never drains in the loop, raw s_barrier) with a schedule laid
+// out for this gather-GEMM:
 //
-//  * waves 2 (M) x 4 (N), each owns 128 x 64 outputs = 2 x 2 quadrants of 64 x 32 = 32 accumulator tiles of
-//    v_mfma_f32_16x16x32_bf16 (128 registers).  A K tile (64 deep) is four PHASES, one quadrant each, 16 MFMAs per phase:
-//        P1 (m0, n0): reads A m0 (8 ds_read_b128) + B n0 (4)      P2 (m0, n1): reads B n1 (4)
-//        P3 (m1, n1): reads A m1 (8)                              P4 (m1, n0): reads nothing (B n0 is still in registers)
+//  * waves 2 (pixels) x 4 (channels), each owns 128 pixels x 64 channels = 2 x 2 quadrants of 64 x 32 = 8 accumulator
+//    tiles of v_mfma_f32_32x32x16_bf16 (128 registers).  The WEIGHTS are the MFMA's A operand (rows = output channels) and
+//    the pixels its B operand (columns), so a lane ends up with 4-channel runs of ONE pixel: the epilogue stores from
+//    registers (below).  32x32x16 rather than 16x16x32: it holds the SIMD's issue port for 8 of its 32 cycles instead of
+//    8 of 16, and the loop lives on the partner wave issuing its loads in those gaps (measured with tools/probe/
+//    bf16_pp_probe: with 16x16x32 the load and multiply sections of the two waves of a SIMD mostly serialised).
+//    A K tile (64 deep) is four PHASES, one quadrant each, 8 MFMAs per phase:
+//        P1 (m0, n0): reads pixels m0 (8 ds_read_b128) + weights n0 (4)      P2 (m0, n1): reads weights n1 (4)
+//        P3 (m1, n1): reads pixels m1 (8)                                    P4 (m1, n0): reads nothing (n0 still in registers)
 //  * a phase is  [LOAD: the phase's fragment reads, ONE 16 KB staging unit by LDS-DMA, s_waitcnt vmcnt(8)]  s_barrier
-//    [16 MFMAs]  s_barrier.  Waves 4-7 run half a phase behind waves 0-3 (one extra barrier up front): on every SIMD one
-//    wave multiplies while its partner loads, so the matrix pipe sees back-to-back clusters.
-//  * LDS: two K tiles x four units of 128 rows x 128 B: A0 / A1 = the m0 / m1 row blocks of BOTH wave rows, B0 / B1 = the
-//    n0 / n1 column blocks of all four wave columns -- a unit is exactly what ONE phase reads, so it can be refilled (for
+//    [8 MFMAs]  s_barrier.  Waves 4-7 run half a phase behind waves 0-3 (one extra barrier up front): on every SIMD one
+//    wave multiplies while its partner loads.
+//  * LDS: two K tiles x four units of 128 rows x 128 B: A0 / A1 = the m0 / m1 pixel blocks of BOTH wave rows, B0 / B1 = the
+//    n0 / n1 channel blocks of all four wave columns -- a unit is exactly what ONE phase reads, so it can be refilled (for
 //    the K tile after next) two phases after that phase: P3(t) stages A0(t+2), P4(t) B0(t+2), P1(t+1) B1(t+2), P2(t+1)
 //    A1(t+2).  Every unit is issued 5-6 phases before its first read; vmcnt(8) = "all but the newest four units have
 //    landed" is the only wait, placed one phase before the read with a barrier in between (RAW), and a unit is re-staged
 //    >= 2 phases after its last read (WAR): the two rules of the guide's template, checked here for both wave groups.
 //  * rows are 128 B with the 16-byte quads XOR-swizzled by (row >> 1) & 7 (applied to the SOURCE address of the DMA and to
-//    the fragment reads): conflict-free ds_read_b128 for the 16-row fragments.
+//    the fragment reads): conflict-free ds_read_b128 for the 32-row fragments.
 //  * K tiles are processed in pairs (static LDS addresses); an odd count is padded with one all-zero tile (DMA lanes
 //    pointed out of range deposit zeros).
-// Epilogue: as above through LDS in fp32 (two passes of 128 rows), 16-byte residual loads and stores.
+// Epilogue from registers: D[row = channel][column = pixel]: lane (pixel l & 31, half h = l >> 5) holds channels
+// 8 g + 4 h + j (g, j = 0..3) of its pixel; v_permlane32_swap between the halves turns two 4-channel runs into one 8-channel
+// run (cdna_hip_programming.md T21) -> bias / leaky-relu / BN affine in fp32, 16-byte residual loads, ONE rounding, 16-byte
+// stores.  No LDS staging, no barrier after the K loop.
 // ---------------------------------------------------------------------------
-typedef float f32x4t __attribute__((ext_vector_type(4)));
-
 #ifdef Y3_TIMING
 __device__ int y3_pp_abl = 0;       // probe only (tools/probe/bf16_pp_probe.hip): 1 no DMA in the loop, 2 no fragment reads, 4 no MFMAs, 8 no vmcnt wait
-#define Y3_PPABL(bit) (y3_pp_abl & (bit))
+#define Y3_PPABL_INIT() const int pp_abl = __builtin_amdgcn_readfirstlane(y3_pp_abl)      /* read ONCE: a reload after every barrier would be timed too */
+#define Y3_PPABL(bit) (pp_abl & (bit))
 #else
+#define Y3_PPABL_INIT()
 #define Y3_PPABL(bit) 0
 #endif
 #define Y3_PP_UNIT 16384                  // 128 rows x 128 B
 #define Y3_PP_TILE (4 * Y3_PP_UNIT)       // A0 | A1 | B0 | B1
-#define Y3_PP_SLD 260                     // fp32 pitch of the epilogue staging tile
-#define Y3_PP_LDS (128 * Y3_PP_SLD * 4 > 2 * Y3_PP_TILE ? 128 * Y3_PP_SLD * 4 : 2 * Y3_PP_TILE)
+#define Y3_PP_LDS (2 * Y3_PP_TILE)
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define Y3_SWAP32(lo, hi)                                                          \
+    do {                                                                           \
+        auto r_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false); \
+        lo = __uint_as_float(r_[0]);                                               \
+        hi = __uint_as_float(r_[1]);                                               \
+    } while (0)
+#else
+#define Y3_SWAP32(lo, hi) ((void)(lo), (void)(hi))
+#endif
 
 __global__ __launch_bounds__(512, 2) void conv_bf16_pp_kernel(const Bf16Args p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[Y3_PP_LDS];
+    Y3_PPABL_INIT();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int r16 = lane & 15, lq = lane >> 4;
+    const int l31 = lane & 31, lh = lane >> 5;
     int nbn = p.nbn, ohw = p.ohw, OW = p.OW, aM = p.M, aH = p.H, aW = p.W, src_ld = p.src_ld, csh = p.sh, csw = p.sw, ntaps = p.ntaps;
     unsigned dn_m = p.dv_nbn.mul, dohw_m = p.dv_ohw.mul, dow_m = p.dv_ow.mul;
     int dn_s = p.dv_nbn.shift, dohw_s = p.dv_ohw.shift, dow_s = p.dv_ow.shift;
@@ -423,8 +442,8 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pp_kernel(const Bf16Args p) 
     const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.wt), 0, p.wt_bytes, 0x00020000);
 
     // ---- staging addresses.  Unit row R = (i * 8 + wave) * 8 + (lane >> 3), slot = lane & 7 (LDS-DMA: lane l lands at
-    // wave base + 16 l); the lane fetches source quad slot ^ f(R).  A unit s: R < 64 -> tile row s*64 + R of wave row 0,
-    // else 128 + s*64 + (R - 64); B unit s: tile column (R >> 5) * 64 + s * 32 + (R & 31).
+    // wave base + 16 l); the lane fetches source quad slot ^ f(R).  A unit s: R < 64 -> tile pixel s*64 + R of wave row 0,
+    // else 128 + s*64 + (R - 64); B unit s: tile channel (R >> 5) * 64 + s * 32 + (R & 31).
     unsigned a_voff[2][2], a_mask[2][2], b_voff[2][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -486,52 +505,47 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pp_kernel(const Bf16Args p) 
         }
     };
 
-    // ---- fragment addresses: 16 rows x (4 quads of one 32-deep K step); lane: row r16, quad lq
-    const int swz = (r16 >> 1) & 7;
-    const int qo0 = ((lq) ^ swz) * 16, qo1 = ((4 + lq) ^ swz) * 16;
-    const unsigned char* a_lane = smem + (wr * 64 + r16) * 128;
-    const unsigned char* b_lane = smem + (wc * 32 + r16) * 128;
-    bf16x8 af[4][2], bfr[2][2][2];      // A: [row tile][k step]; B: [n sub][col tile][k step]
-    f32x4t acc[2][4][2][2];             // [m sub][row tile][n sub][col tile]
+    // ---- fragment addresses: 32 rows x (2 quads of one 16-deep K step); lane: row l31, quad 2 ks + lh
+    const int swz = (l31 >> 1) & 7;
+    int qo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qo[ks] = ((2 * ks + lh) ^ swz) * 16;
+    const unsigned char* a_lane = smem + (wr * 64 + l31) * 128;
+    const unsigned char* b_lane = smem + (wc * 32 + l31) * 128;
+    bf16x8 pf[2][4], wf[2][4];          // pixels: [pixel tile][k step]; weights: [n sub][k step]
+    f32x16 acc[2][2][2];                // [m sub][pixel tile][n sub]: D[row = channel][column = pixel]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4t{0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
 
     auto read_a = [&](int buf, int s) {
         if (Y3_PPABL(2)) return;
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-            const unsigned char* q = a_lane + buf * Y3_PP_TILE + s * Y3_PP_UNIT + rt * 2048;
-            af[rt][0] = *reinterpret_cast<const bf16x8*>(q + qo0);
-            af[rt][1] = *reinterpret_cast<const bf16x8*>(q + qo1);
+        for (int pt = 0; pt < 2; ++pt) {
+            const unsigned char* q = a_lane + buf * Y3_PP_TILE + s * Y3_PP_UNIT + pt * 4096;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) pf[pt][ks] = *reinterpret_cast<const bf16x8*>(q + qo[ks]);
         }
     };
     auto read_b = [&](int buf, int s) {
         if (Y3_PPABL(2)) return;
+        const unsigned char* q = b_lane + buf * Y3_PP_TILE + (2 + s) * Y3_PP_UNIT;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const unsigned char* q = b_lane + buf * Y3_PP_TILE + (2 + s) * Y3_PP_UNIT + ct * 2048;
-            bfr[s][ct][0] = *reinterpret_cast<const bf16x8*>(q + qo0);
-            bfr[s][ct][1] = *reinterpret_cast<const bf16x8*>(q + qo1);
-        }
+        for (int ks = 0; ks < 4; ++ks) wf[s][ks] = *reinterpret_cast<const bf16x8*>(q + qo[ks]);
     };
     auto mma = [&](auto SM, auto SN) {
         constexpr int sm = decltype(SM)::value, sn = decltype(SN)::value;
         if (Y3_PPABL(4)) return;
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    acc[sm][rt][sn][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rt][ks], bfr[sn][ct][ks], acc[sm][rt][sn][ct], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+            for (int pt = 0; pt < 2; ++pt)
+                acc[sm][pt][sn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[sn][ks], pf[pt][ks], acc[sm][pt][sn], 0, 0, 0);
     };
     auto load_end = [&]() {       // end of a LOAD section: all but the newest four units have landed; the group barrier
         if (!Y3_PPABL(8)) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
@@ -597,74 +611,74 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pp_kernel(const Bf16Args p) 
         tile(I1{}, 2 * it + 1, k1, k2);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();   // barrier counts of the two groups match again
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): no DMA may land in the block the epilogue re-uses
-    __syncthreads();
     Y3_TSTAMP(2);
 
-    // ---- epilogue.  D layout of 16x16 tiles: column = lane & 15 (channel), row = 4 * (lane >> 4) + reg.
-    float* stage = reinterpret_cast<float*>(smem);
+    // ---- epilogue from registers (the DMA still in flight only ever targets LDS, which is not touched again).
+    // Tile (sm, pt, sn): pixel = m0 + wr*128 + sm*64 + pt*32 + l31; register r = 4 g + j is channel cb + 8 g + 4 lh + j with
+    // cb = n0 + wc*64 + sn*32.  Swapping (g even, lanes >= 32) <-> (g odd, lanes < 32) leaves lanes < 32 with the 8 channels
+    // cb + 16 e .. + 7 and lanes >= 32 with cb + 16 e + 8 .. + 15 (e = g / 2) of their pixel.
     const bool do_lrelu = p.flags & Y3_EPI_LRELU;
     const bool has_scale = p.scale != nullptr, has_resid = p.resid != nullptr;
-    float bias[2][2], sc[2][2], sf[2][2];
-#pragma unroll
-    for (int sn = 0; sn < 2; ++sn)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const int n = n0 + wc * 64 + sn * 32 + ct * 16 + r16;
-            const bool nok = n < p.Nout;
-            bias[sn][ct] = (p.bias && nok) ? p.bias[n] : 0.f;
-            sc[sn][ct] = (has_scale && nok) ? p.scale[n] : 1.f;
-            sf[sn][ct] = (has_scale && nok) ? p.shift[n] : 0.f;
-        }
     const char* resid_b = reinterpret_cast<const char*>(p.resid);
     char* dst_b = reinterpret_cast<char*>(p.dst);
 #pragma unroll
-    for (int sm = 0; sm < 2; ++sm) {
-        // staged row = wr * 64 + rt * 16 + 4 * lq + reg  <->  tile row wr * 128 + sm * 64 + (staged row & 63)
+    for (int sn = 0; sn < 2; ++sn) {
+        const int cb = n0 + wc * 64 + sn * 32;
+        f32x4 bias[4], sc[4], sf[4];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int g = 0; g < 4; ++g) {
+            const int c = cb + 8 * g + 4 * lh;
+            const bool cok = c < p.Nout;      // Nout % 8 == 0: a 4-channel run is inside or outside
+            bias[g] = (p.bias && cok) ? *reinterpret_cast<const f32x4*>(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            sc[g] = (has_scale && cok) ? *reinterpret_cast<const f32x4*>(p.scale + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+            sf[g] = (has_scale && cok) ? *reinterpret_cast<const f32x4*>(p.shift + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-            for (int sn = 0; sn < 2; ++sn)
+        for (int sm = 0; sm < 2; ++sm)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
+            for (int pt = 0; pt < 2; ++pt) {
+                const int m = m0 + wr * 128 + sm * 64 + pt * 32 + l31;
+                float v[16];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[sm][rt][sn][ct][r] + bias[sn][ct];
-                        if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
-                        if (has_scale) v = v * sc[sn][ct] + sf[sn][ct];
-                        stage[(wr * 64 + rt * 16 + 4 * lq + r) * Y3_PP_SLD + wc * 64 + sn * 32 + ct * 16 + r16] = v;
+                for (int r = 0; r < 16; ++r) {
+                    float x = acc[sm][pt][sn][r] + bias[r >> 2][r & 3];
+                    if (do_lrelu) x = x > 0.f ? x : p.alpha * x;
+                    if (has_scale) x = x * sc[r >> 2][r & 3] + sf[r >> 2][r & 3];
+                    v[r] = x;
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Y3_SWAP32(v[8 * e + j], v[8 * e + 4 + j]);
+                    // lanes < 32: v[8e .. 8e+3] = own channels cb+16e+0..3, v[8e+4 .. +7] = the upper half's cb+16e+4..7
+                    // lanes >= 32: v[8e .. +3] = the lower half's cb+16e+8..11, v[8e+4 .. +7] = own cb+16e+12..15
+                    const int n = cb + 16 * e + 8 * lh;
+                    if (m < p.M && n < p.Nout) {
+                        float* w = v + 8 * e;
+                        if (has_resid) {
+                            const uint4 rv = *reinterpret_cast<const uint4*>(resid_b + ((size_t)m * p.resid_ld + n) * 2);
+                            const unsigned rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                w[2 * q] += __uint_as_float(rw[q] << 16);
+                                w[2 * q + 1] += __uint_as_float(rw[q] & 0xffff0000u);
+                            }
+                        }
+                        if (p.out_f32) {
+                            float* d = reinterpret_cast<float*>(dst_b + ((size_t)m * p.dst_ld + n) * 4);
+                            *reinterpret_cast<f32x4*>(d) = f32x4{w[0], w[1], w[2], w[3]};
+                            *reinterpret_cast<f32x4*>(d + 4) = f32x4{w[4], w[5], w[6], w[7]};
+                        } else {
+                            unsigned pk[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) pk[q] = (unsigned)f32_to_bf16(w[2 * q]) | ((unsigned)f32_to_bf16(w[2 * q + 1]) << 16);
+                            *reinterpret_cast<uint4*>(dst_b + ((size_t)m * p.dst_ld + n) * 2) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                        }
                     }
-        __syncthreads();
-#pragma unroll 2
-        for (int idx = tid; idx < 128 * 32; idx += 512) {
-            const int row = idx >> 5, c8 = (idx & 31) * 8;
-            const int m = m0 + (row >> 6) * 128 + sm * 64 + (row & 63), n = n0 + c8;
-            if (m >= p.M || n >= p.Nout) continue;
-            const float* sp = stage + row * Y3_PP_SLD + c8;
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(sp), hi = *reinterpret_cast<const f32x4*>(sp + 4);
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            if (has_resid) {
-                const uint4 rv = *reinterpret_cast<const uint4*>(resid_b + ((size_t)m * p.resid_ld + n) * 2);
-                const unsigned rw[4] = {rv.x, rv.y, rv.z, rv.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[2 * e] += __uint_as_float(rw[e] << 16);
-                    v[2 * e + 1] += __uint_as_float(rw[e] & 0xffff0000u);
                 }
             }
-            if (p.out_f32) {
-                float* d = reinterpret_cast<float*>(dst_b + ((size_t)m * p.dst_ld + n) * 4);
-                *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
-            } else {
-                unsigned pk[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = (unsigned)f32_to_bf16(v[2 * e]) | ((unsigned)f32_to_bf16(v[2 * e + 1]) << 16);
-                *reinterpret_cast<uint4*>(dst_b + ((size_t)m * p.dst_ld + n) * 2) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-            }
-        }
-        if (sm == 0) __syncthreads();
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // the (zero-filling) DMA of the padded tail must not outlive the workgroup's LDS
 #ifdef Y3_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
