@@ -1454,6 +1454,23 @@ static ConvPlan plan_conv(int M, int Nout, int K, bool fast_ok) {
     }
     return pl;
 }
+// Debug switch of the product library (documented in yolo3hip.h): with Y3_CHECK_TICKETS=1 every launch that uses the ticket
+// header first synchronises the stream and verifies that the header is all zero -- a workspace that was never zeroed (or was
+// shared between two streams) otherwise shows up only as stale output: no slice ever draws the "last" ticket.
+static int check_tickets(const char* what, const void* workspace, hipStream_t st) {
+    static const int on = getenv("Y3_CHECK_TICKETS") ? atoi(getenv("Y3_CHECK_TICKETS")) : 0;
+    if (!on || !workspace) return Y3_OK;
+    if (hipStreamSynchronize(st) != hipSuccess) return Y3_OK;
+    static int* host = (int*)malloc(Y3_WS_HEADER);
+    if (!host || hipMemcpy(host, workspace, Y3_WS_HEADER, hipMemcpyDeviceToHost) != hipSuccess) return Y3_OK;
+    for (int i = 0; i < Y3_MAX_TICKETS; ++i)
+        if (host[i] != 0) {
+            y3_set_error("%s: ticket %d of the workspace header is %d, not 0: zero the workspace once after allocating it and keep its "
+                         "launches on one stream (include/yolo3hip.h, workspace contract)", what, i, host[i]);
+            return Y3_EINVAL;
+        }
+    return Y3_OK;
+}
 static bool fast_shape_ok(int C, int Nout, int K, int ntaps) {
     return !getenv("Y3_NO_FAST") && C % 16 == 0 && K % 16 == 0 && (ntaps == 1 || y3_is_pow2(C));
 }
@@ -1626,6 +1643,8 @@ static int launch_igemm(const ConvArgs& a, void* workspace, size_t workspace_byt
         f.sk_chunk1 = pl.chunk1;
         f.sk_slab0 = pl.s0 > 1 ? 0 : f.sk_n0;
         f.tickets = pl.ws_bytes ? (int*)workspace : nullptr;
+        if (f.tickets)
+            if (int e = check_tickets("conv2d", workspace, st)) return e;
         f.slab = pl.ws_bytes ? (float*)((char*)workspace + Y3_WS_HEADER) : nullptr;
         const int grid = f.sk_n0 + (tiles - pl.f) * pl.s1;
         const bool dense = p.dense_dst != 0;
@@ -2118,22 +2137,31 @@ extern "C" int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int 
     Y3_CHECK_ARG(need < 0x7ff00000ull, "conv2d_wgrad: slab area too large (%zu bytes)", need);
     const bool in_kernel = wgrad_in_kernel(w);
     p.tickets = in_kernel ? (int*)workspace : nullptr;
+    if (p.tickets)
+        if (int e = check_tickets("conv2d_wgrad", workspace, (hipStream_t)stream)) return e;
     p.out = w.splits > 1 ? (float*)((char*)workspace + Y3_WS_HEADER) : dw;
     p.dw = dw;
     hipStream_t st = (hipStream_t)stream;
     p.tiles = w.tiles;
     p.splits = w.splits;
     dim3 grid((unsigned)((w.splits >= 32 ? y3_cdiv(w.splits, 8) * 8 : w.splits) * w.tiles));
+    // Unused dynamic LDS on top of the kernel's static 40 KB: the kernel gradients run on the second stream beside the
+    // BatchNorm-backward kernels of the compute stream, and the 128x64 / 64x128 variants otherwise fill all
+    // 160 KB of a CU with 4 workgroups -- the 12 KB bn_bwd_finalize_tiles kernel on the critical path then waits for one of
+    // them to retire (20 us per launch in the overlapped step against 9.7 us alone).  8 KB of pad caps them at 3 workgroups
+    // per CU (the occupancy their register budget aims at): step 18.21 -> 18.03 ms (tools/ab_wgrad_pad.sh, two rounds;
+    // padding the 32 KB 64x64 variant as well: no further change).
+    static const int pad40 = env_int("Y3_WGRAD_PAD40", 8192), pad32 = env_int("Y3_WGRAD_PAD32", 0);
     if (w.bkr == 128 && w.bn == 128)
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 16>), grid, dim3(256), 0, st, p);
     else if (w.bkr == 128 && w.bn == 64)
-        hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 4, 1, 16>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 4, 1, 16>), grid, dim3(256), pad40, st, p);
     else if (w.bkr == 128 && w.bn == 32)
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 4, 1, 16>), grid, dim3(256), 0, st, p);
     else if (w.bkr == 64 && w.bn == 128)
-        hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2, 16>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2, 16>), grid, dim3(256), pad40, st, p);
     else if (w.bkr == 64 && w.bn == 64)
-        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, 16>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, 16>), grid, dim3(256), pad32, st, p);
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<64, 32, 2, 1, 16>), grid, dim3(128), 0, st, p);
     Y3_CHECK_LAUNCH("conv_wgrad");

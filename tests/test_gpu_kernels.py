@@ -546,6 +546,39 @@ def test_errors_are_reported(hip):
         hip.check(rc, 'y3_conv2d_fwd')
 
 
+def test_dirty_ticket_header_is_detected(tmp_path):
+    """a conv workspace whose ticket header was never zeroed fails silently (stale output, Y3_OK).  With
+    Y3_CHECK_TICKETS=1 the launch reports it.  In a process of its own: the switch is read once per process."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from yolo3 import _hip
+lib = _hip.lib
+n, h, w, cin, cout, k = 2, 13, 13, 512, 1024, 3
+x = torch.randn(n, h, w, cin, device="cuda")
+wt = torch.randn(k * k * cin * cout, device="cuda") * 0.02
+b = torch.zeros(cout, device="cuda")
+y = torch.empty(n, h, w, cout, device="cuda")
+wsb = int(lib.y3_conv2d_fwd_workspace(n * h * w, cin, k, cout))
+assert wsb > 0
+st = torch.cuda.current_stream().cuda_stream
+src, dst = _hip.Tensor(x.data_ptr(), n, h, w, cin, cin), _hip.Tensor(y.data_ptr(), n, h, w, cout, cout)
+run = lambda ws: lib.y3_conv2d_fwd(src, wt.data_ptr(), b.data_ptr(), k, 1, dst, 1, 0.2, None, None, None, None, ws.data_ptr(), wsb, st)
+good = torch.zeros(wsb // 4 + 4, device="cuda")
+assert run(good) == 0 and run(good) == 0                      # a zeroed header stays zero: launch after launch
+bad = torch.zeros(wsb // 4 + 4, device="cuda")
+bad.view(torch.int32)[7] = 3                                  # one stale ticket
+rc = run(bad)
+msg = lib.y3_last_error().decode()
+assert rc == -1 and "ticket 7" in msg and "is 3" in msg, (rc, msg)
+print("detected:", msg[:60])
+''' % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'object-detection-yolov3_amd')
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, Y3_CHECK_TICKETS='1'), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'detected:' in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+
+
 def test_decode_matches_oracle(hip):
     """y3_decode_fwd vs oracle.model.decode (fp64); 1e-5 relative to the box scale."""
     from oracle import model as om

@@ -7,12 +7,20 @@ oracle itself -- |gpu - oracle_fp64| must stay within a small multiple of
 |oracle_fp32 - oracle_fp64| (the rounding noise any fp32 implementation of the
 same graph shows), plus 1e-5 of the tensor's scale.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
+# Absolute part of the model-level gradient bound  err <= 6 x (oracle fp32-vs-fp64 rel. L2) + GRAD_FLOOR.  What the runs measure
+# (gpurun_out/train_step_grad_err_*.json, round 3, 294 tensors): at 416 x 8 the largest rel. L2 error is 1.5e-2 against an oracle
+# fp32 noise of up to 1.6e-2 (medians 1.0e-2 / 1.1e-2) and the largest excess over 6 x noise is 2.1e-3; at 96 x 4: 6.6e-2 / 3.8e-2,
+# excess 6.7e-4.  The floor is ~2.4 x the largest excess.  The per-kernel tests (2e-5 .. 1e-4 against fp64) carry the real weight:
+# this test checks that the 370-launch plan wires them into the right graph.
+GRAD_FLOOR = 5e-3
 ANCHORS = [(64, 384), (384, 64)]
 K = 2
 
@@ -197,11 +205,21 @@ def test_train_step_matches_oracle(img, n):
     # two fp32 evaluations of the same graph differ by a few per cent in max-norm on tensors with few pixels
     # (the fp32 and fp64 oracles do, too).  Compare in relative L2 against the oracle's own fp32-vs-fp64 gap;
     # each kernel is checked to 1e-4..2e-5 in isolation by test_gpu_kernels.py.
+    report = []
     for i, (g, a, b) in enumerate(zip(flat, r32['grads'], r64['grads'])):
         a, b, g = a.numpy().astype(np.float64), b.numpy(), np.asarray(g, np.float64)
         nb = np.linalg.norm(b) + 1e-30
         noise, err = np.linalg.norm(a - b) / nb, np.linalg.norm(g - b) / nb
-        assert np.isfinite(g).all() and err <= 6.0 * noise + 5e-3, 'grad tensor %d: rel L2 err %.3e (oracle fp32 noise %.3e)' % (i, err, noise)
+        report.append((err, noise))
+        assert np.isfinite(g).all() and err <= 6.0 * noise + GRAD_FLOOR, 'grad tensor %d: rel L2 err %.3e (oracle fp32 noise %.3e)' % (i, err, noise)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out_dir):      # what this run measured (the floor above is 2 x the largest excess seen: see GRAD_FLOOR)
+        import json
+        errs, noises = np.array([r[0] for r in report]), np.array([r[1] for r in report])
+        with open(os.path.join(out_dir, 'train_step_grad_err_%d_%d.json' % (img, n)), 'w') as fh:
+            json.dump(dict(tensors=len(report), max_rel_l2_err=float(errs.max()), median_rel_l2_err=float(np.median(errs)),
+                           max_oracle_fp32_noise=float(noises.max()), median_oracle_fp32_noise=float(np.median(noises)),
+                           max_excess_over_6x_noise=float((errs - 6.0 * noises).max())), fh)
     # moving statistics after the first forward depend on the initial weights only
     mov = [(d['mean'], d['var']) for d in yolo.get_weights() if 'mean' in d]
     for i, ((m, v), (m32, v32), (m64, v64)) in enumerate(zip(mov, res[torch.float32][1][0][1], res[torch.float64][1][0][1])):
