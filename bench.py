@@ -52,17 +52,19 @@ def tiled_4k(use_graph):
     y = YoloV3(25, [608, 608, 3], K, ANCHORS, seed=1, use_graph=use_graph)
     big = np.random.default_rng(4).integers(0, 256, (4096, 4096, 3), dtype=np.uint8)
     tile_fl = conv_flops_per_image(y.specs, 608)[0]
-    out = {'image': [4096, 4096, 3], 'tile': [608, 608], 'tiles': 100, 'batch': 25}
+    tb = int(os.environ.get('Y3_TILED_BATCH', '0')) or None      # experiments: fixed tiles per launch instead of the planned batches
+    out = {'image': [4096, 4096, 3], 'tile': [608, 608], 'tiles': 100,
+           'batches': {'bf16': inference_tiled.plan_tile_batches(100, [608, 608]), 'fp32': [25, 25, 25, 25]}}
     for prec in ('bf16', 'fp32'):      # bf16 first: its buffers then come out of untouched GPU memory (measured: the figure is bimodal, 30 / 38 ms, with the memory the allocator hands out)
         y.inference_precision = prec
         mdl = y.get_keras_model()
         with contextlib.redirect_stdout(io.StringIO()):
-            inference_tiled.inference_image_tiled(mdl, big, [608, 608], 32, batch_size=25)
+            inference_tiled.inference_image_tiled(mdl, big, [608, 608], 32, batch_size=tb)
             torch.cuda.synchronize()
             times = []
             for _ in range(5):      # every image timed on its own: the path is host-driven (upload, launches on two streams, merge),
                 t1 = time.perf_counter()      # and one slow repetition on a shared box moved a 3-image mean from 30.4 to 38.8 ms
-                inference_tiled.inference_image_tiled(mdl, big, [608, 608], 32, batch_size=25)
+                inference_tiled.inference_image_tiled(mdl, big, [608, 608], 32, batch_size=tb)
                 torch.cuda.synchronize()
                 times.append(time.perf_counter() - t1)
         t = sorted(times)[len(times) // 2]

@@ -128,9 +128,40 @@ def finalize_predictions(boxes_list, scores_list, class_label_list, img_size):
     return np.concatenate((boxes, scores, class_label), axis=-1)
 
 
-def inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size=BATCH_SIZE):
+def plan_tile_batches(n_tiles, tile_size, compute_units=256):
+    """How many tiles go into each network launch on the bf16 conv path.  The layers that carry the FLOPs run on 256 x 256
+    output tiles, one workgroup per CU (csrc/conv_bf16.hip, conv_bf16_pp_kernel), so a launch costs whole ROUNDS of 256
+    workgroups: a batch of 25 tiles of 608^2 is 565 workgroups on the /8 stage -- three rounds for 2.2 rounds of work.  The
+    cost of a batch of B tiles is modelled as  sum over the /8, /16, /32 stages of  (3x3 layers of the stage) x (relative K
+    of a workgroup) x ceil(row tiles x column tiles / CUs),  and the batch size that minimises the cost of all n_tiles
+    (remainder batch included) is taken: 45 + 45 + 10 for the 100 tiles of a 4096^2 image at 608^2 (measured network rate
+    on MI355X: 3 660 tiles/s at 25, 4 520 at 44).  Returns the list of batch sizes."""
+    th, tw = int(tile_size[0]), int(tile_size[1])
+
+    def cost(b):
+        c = 0
+        for stride, col_tiles, weight in ((8, 1, 11 * 1), (16, 2, 11 * 2), (32, 4, 7 * 4)):
+            rows = -(-(b * (th // stride) * (tw // stride)) // 256)
+            c += weight * -(-(rows * col_tiles) // compute_units)
+        return c
+
+    best = None
+    for b in range(4, 65):
+        full, rem = divmod(n_tiles, b)
+        total = full * cost(b) + (cost(rem) if rem else 0)
+        if best is None or total < best[0]:
+            best = (total, b)
+    b = min(best[1], n_tiles) if n_tiles > 0 else 1
+    out = [b] * (n_tiles // b)
+    if n_tiles % b:
+        out.append(n_tiles % b)
+    return out
+
+
+def inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size=None):
     """inference_tiled.py:185-310.  ``yolo_model(batch, training=False)`` maps CUDA float32 [B,C,h,w] (z-scored) to
-    rows [B, Nb, 5+K] (CUDA tensor or ndarray)."""
+    rows [B, Nb, 5+K] (CUDA tensor or ndarray).  batch_size None: BATCH_SIZE tiles per launch on the fp32 path,
+    plan_tile_batches() on the bf16 path."""
     img_size = img.shape
     # the image goes to the GPU once, in its own dtype; cropping, reflect padding, astype(float32) and HWC -> CHW of
     # convert_image_to_tiles (inference_tiled.py:29-100,199-203) happen there, one launch per batch of tiles
@@ -165,9 +196,18 @@ def inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size=B
             img_dev.record_stream(s)
             table_dev.record_stream(s)
     queued = []
-    for bi, b0 in enumerate(range(0, len(xs), batch_size)):
+    if batch_size is None:
+        bf16 = getattr(getattr(yolo_model, '_y', None), 'inference_precision', 'fp32') == 'bf16'
+        sizes = plan_tile_batches(len(xs), tile_size) if bf16 else None
+        batch_size = BATCH_SIZE
+    else:
+        sizes = None
+    if sizes is None:
+        sizes = [min(batch_size, len(xs) - b0) for b0 in range(0, len(xs), batch_size)]
+    starts = [sum(sizes[:i]) for i in range(len(sizes))]
+    for bi, (b0, nb) in enumerate(zip(starts, sizes)):
         with torch.cuda.stream(streams[bi % slots]):
-            x = tiles_to_device(img_dev, code, img_size, table_dev, b0, min(batch_size, len(xs) - b0), tile_size)
+            x = tiles_to_device(img_dev, code, img_size, table_dev, b0, nb, tile_size)
             x = imagereader.zscore_normalize_device(x)                   # per TILE statistics (inference_tiled.py:205, Q12)
             rows = yolo_model(x, training=False, slot=bi % slots) if slots > 1 else yolo_model(x, training=False)
             rows = torch.as_tensor(rows, dtype=torch.float32).cuda().clone()   # the slot's output buffer is reused two batches later
@@ -182,7 +222,7 @@ def inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size=B
 
 
 def inference_image_folder(image_folder, image_format, saved_model_filepath, output_folder, tile_size, min_roi_size, precision='fp32',
-                           batch_size=BATCH_SIZE):
+                           batch_size=None):
     if not os.path.exists(saved_model_filepath):
         raise RuntimeError('Missing saved_model_filepath File')
     if image_format.startswith('.'):
@@ -221,6 +261,6 @@ if __name__ == '__main__':
     parser.add_argument('--tile-width', type=int, default=512)
     parser.add_argument('--min-box-size', type=int, default=32)
     parser.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32', help='conv arithmetic (extension; the reference is fp32)')
-    parser.add_argument('--batch-size', type=int, default=BATCH_SIZE, help='tiles per network launch (extension)')
+    parser.add_argument('--batch-size', type=int, default=None, help='tiles per network launch (extension; default: %d on the fp32 path, planned per image on the bf16 path)' % BATCH_SIZE)
     a = parser.parse_args()
     inference_image_folder(a.image_folder, a.image_format, a.saved_model_filepath, a.output_folder, [a.tile_height, a.tile_width], a.min_box_size, a.precision, a.batch_size)

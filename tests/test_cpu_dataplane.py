@@ -296,3 +296,22 @@ def test_ltrbc_writer_and_inverse_format_boxes_match_reference(golden_dir, tmp_p
     assert np.argwhere(l3[..., 4] > 0).tolist() == j['label3_nonzero']
     inv = imagereader.inverse_format_boxes(np.stack([l3, l3]), 1)
     assert np.asarray(inv).tolist() == j['inverse']
+
+
+def test_tile_batch_planner():
+    """inference_tiled.plan_tile_batches (host logic of the bf16 tiled path): batches cover every tile once, whole rounds of
+    256 workgroups at the 256 x 256-tile stages, small images stay one batch."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('inference_tiled_for_test', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'object-detection-yolov3_amd', 'inference_tiled.py'))
+    it = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(it)
+    except Exception as e:                   # the module imports the HIP binding at the top: nothing to test without the library
+        pytest.skip('inference_tiled not importable here: %s' % e)
+    assert it.plan_tile_batches(100, [608, 608]) == [45, 45, 10]
+    for n in (0, 1, 7, 9, 16, 36, 64, 99, 100, 101, 400):
+        for tile in ([608, 608], [512, 512], [416, 416], [608, 352]):
+            b = it.plan_tile_batches(n, tile)
+            assert sum(b) == n and all(0 < v <= 64 for v in b) and len(set(b[:-1])) <= 1
+    # 45 tiles of 608^2: 1016 / 508 / 256 workgroups = 3.97 / 1.98 / 1.0 rounds of 256
+    assert [-(-(45 * (608 // s) ** 2) // 256) * c for s, c in ((8, 1), (16, 2), (32, 4))] == [1016, 508, 256]

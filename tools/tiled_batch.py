@@ -17,7 +17,7 @@ import inference_tiled           # noqa: E402
 big = np.random.default_rng(4).integers(0, 256, (4096, 4096, 3), dtype=np.uint8)
 for bs in [int(v) for v in (sys.argv[1:] or ["8", "16", "25", "34", "50"])]:
     y = YoloV3(bs, [608, 608, 3], 2, bench.ANCHORS, seed=1, use_graph=True)
-    for prec in ('fp32', 'bf16'):
+    for prec in (('bf16',) if os.environ.get('Y3_SWEEP_BF16_ONLY') else ('fp32', 'bf16')):
         y.inference_precision = prec
         mdl = y.get_keras_model()
         with contextlib.redirect_stdout(io.StringIO()):
