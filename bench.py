@@ -385,7 +385,7 @@ def main():
     # WRITE_SIZE; see profiles/README.md): bench.py cannot run the profiler on itself, so it reports the figure committed in
     # the SAME round as the kernels it times (profiles/rNN_traffic.json, newest first) and says which file it was
     traffic, traffic_src = None, None
-    for tag in ('r02', 'r01'):
+    for tag in ('r03', 'r02', 'r01'):
         try:
             with open(os.path.join(ROOT, 'profiles', '%s_traffic.json' % tag)) as fh:
                 traffic = json.load(fh).get('conv_family_hbm_bytes_per_step')

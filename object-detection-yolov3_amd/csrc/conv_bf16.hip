@@ -698,7 +698,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float* __restrict__ src, int src_ld, const float* __restrict__ wt,
                                                               const float* __restrict__ bias, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, u16* __restrict__ dst, int dst_ld, int N, int H,
-                                                              int W, unsigned flags, float alpha) {
+                                                              int W, unsigned flags, float alpha, unsigned src_bytes) {
     __shared__ __attribute__((aligned(16))) float ws[9 * 4 * 32];
     for (int i = threadIdx.x; i < 9 * 4 * 32; i += 256) ws[i] = wt[i];
     __syncthreads();
@@ -715,17 +715,32 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float* __res
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[p][c] = f32x2{0.f, 0.f};
-#pragma unroll 1
-    for (int kh = 0; kh < 3; ++kh) {
+    // Pixel loads through a buffer descriptor: out-of-image pixels point past num_records and come back as zeros, so the six
+    // loads of a row are branch-free and in flight together (the predicated `cond ? *p : 0` form compiled to a branch and a
+    // full memory wait PER LOAD: 18 serialised round trips per thread, 3x off the VALU bound of this kernel).
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
+    // ... and the loads of row kh + 1 are issued before row kh is multiplied (one loop body, two row buffers).
+    auto load_row = [&](f32x4 (&r)[6], int kh) {
         const int ih = oh + kh - 1;
-        if ((unsigned)ih >= (unsigned)H) continue;
-        const float* row = src + (rowi + (kh - 1)) * (long long)W * src_ld;
-        float4 x[6];
+        const bool rok = kh < 3 && (unsigned)ih < (unsigned)H;       // kh = 3: the prefetch of the last iteration fetches nothing
+        const unsigned row_off = (unsigned)((rowi + (kh - 1)) * (long long)W * src_ld * 4);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int iw = ow0 - 1 + i;
-            x[i] = ((unsigned)iw < (unsigned)W) ? *reinterpret_cast<const float4*>(row + (long long)iw * src_ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+            r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, (rok && (unsigned)iw < (unsigned)W) ? row_off + (unsigned)(iw * src_ld * 4) : Y3_OOB, 0, 0);
         }
+    };
+    f32x4 xn[6], xc[6];
+    load_row(xn, 0);
+#pragma unroll 1
+    for (int kh = 0; kh < 3; ++kh) {
+        float4 x[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            xc[i] = xn[i];
+            x[i] = make_float4(xc[i][0], xc[i][1], xc[i][2], xc[i][3]);
+        }
+        load_row(xn, kh + 1);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
             const float* w = ws + (kh * 3 + kw) * 128 + cg;
@@ -975,8 +990,9 @@ extern "C" int y3_conv2d_first_bf16(const y3_tensor* src, const float* wt, const
     Y3_CHECK_ARG((src->w & 3) == 0, "conv2d_first_bf16: width %d must be a multiple of 4", src->w);
     Y3_CHECK_ARG((scale == nullptr) == (shift == nullptr), "conv2d_first_bf16: scale/shift must both be given");
     const long long npix = (long long)src->n * src->h * src->w;
+    Y3_CHECK_ARG(npix * src->ld * 4 < 0x7fffffffLL, "conv2d_first_bf16: input of 2 GiB or more (split the batch)");
     hipLaunchKernelGGL(conv_first_bf16_kernel, dim3(y3_cdiv(npix / 4, 64)), dim3(256), 0, (hipStream_t)stream, (const float*)src->ptr, src->ld, wt, bias,
-                       scale, shift, (u16*)dst->ptr, dst->ld, src->n, src->h, src->w, flags, alpha);
+                       scale, shift, (u16*)dst->ptr, dst->ld, src->n, src->h, src->w, flags, alpha, (unsigned)(npix * src->ld * 4));
     Y3_CHECK_LAUNCH("conv_first_bf16");
     return Y3_OK;
 }

@@ -43,8 +43,9 @@ def load(path, counter=None, mult=1.0):
             k = short(r['Kernel_Name'])
             if not k or (counter and r.get('Counter_Name') != counter):
                 continue
-            grid = int(r['Grid_Size']) if 'Grid_Size' in r else int(r['Grid_Size_X'])
-            wg = int(r['Workgroup_Size']) if 'Workgroup_Size' in r else int(r['Workgroup_Size_X'])
+            # the trace reports per-axis sizes, the counter file their products
+            grid = int(r['Grid_Size']) if 'Grid_Size' in r else int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z'])
+            wg = int(r['Workgroup_Size']) if 'Workgroup_Size' in r else int(r['Workgroup_Size_X']) * int(r['Workgroup_Size_Y']) * int(r['Workgroup_Size_Z'])
             val = float(r['Counter_Value']) * 1024.0 * mult if counter else float(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
             order = int(r['Start_Timestamp']) if not counter else int(r.get('Dispatch_Id', len(rows)))
             rows.append((order, (k, grid, wg), val))

@@ -4,7 +4,7 @@
 # bench.py reads profiles/<tag>_traffic.json for roofline.traffic: after a conv change, copy the new traffic.json first and run
 # bench.py once more for the committed bench line.
 set -e -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -24,9 +24,14 @@ python tools/trace_union.py $(find $OUT/stats -name "*kernel_trace.csv") > $OUT/
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc -o p --output-format csv -- python3 tools/conv_tune.py > $OUT/pmc_conv_tune.txt 2> $OUT/rocprof_pmc.err
 python tools/pmc_summary.py $(find $OUT/pmc -name "*counter_collection.csv") conv_ > $OUT/pmc_conv.txt
 python tools/mfma_util.py $(find $OUT/pmc -name "*counter_collection.csv") conv_ > $OUT/mfma_util_conv.md
+# bf16: the 8 x 608^2 forward and the 45-tile batch the tiled path plans for a 4k image (conv_bf16_pp_kernel layers)
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmcb -o p --output-format csv -- python3 tools/bf16_probe.py > $OUT/pmc_bf16_probe.txt 2> $OUT/rocprof_pmcb.err
 python tools/pmc_summary.py $(find $OUT/pmcb -name "*counter_collection.csv") conv_bf16 > $OUT/pmc_bf16.txt
-python tools/mfma_util.py $(find $OUT/pmcb -name "*counter_collection.csv") conv_bf16 > $OUT/mfma_util_bf16.md
+(echo "## 8 x 608^2 forward"; python tools/mfma_util.py $(find $OUT/pmcb -name "*counter_collection.csv") conv_bf16) > $OUT/mfma_util_bf16.md
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmcb45 -o p --output-format csv -- python3 tools/bf16_probe.py 45 > $OUT/pmc_bf16_probe45.txt 2> $OUT/rocprof_pmcb45.err
+(echo; echo "## 45 x 608^2 forward (one planned batch of the tiled 4k path)"; python tools/mfma_util.py $(find $OUT/pmcb45 -name "*counter_collection.csv") conv_bf16) >> $OUT/mfma_util_bf16.md
+python tools/bf16_ab.py 45 608 --layers > $OUT/bf16_layers_45x608.txt 2>&1
+bash tools/profile_hbm_path.sh $TAG > $OUT/hbm_path.log 2>&1
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -size +20M -delete
 ls -la $OUT $OUT/stats
