@@ -489,7 +489,7 @@ def main():
                        'launch': 'hip-graph' if use_graph else 'host launches, kernel gradients on a second stream', 'parallelism': 'dp%d' % world},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': 'conv_igemm_fast_kernel + conv_wgrad_kernel (MFMA implicit-GEMM conv fwd/dgrad/wgrad, split-K reduced in-kernel), %d launches/step; achieved = flops / union of their busy intervals' % sum(v[1] for v in per.values()),
+                         'kernel': 'conv_igemm_fast_kernel + conv_wgrad_kernel (MFMA implicit-GEMM conv fwd/dgrad/wgrad; split-K and kernel gradients of <= 8 pixel splits reduced in-kernel, the others followed by slab_reduce_kernel inside the same entry), %d entry calls/step; achieved = flops / union of their busy intervals' % sum(v[1] for v in per.values()),
                          'peak_note': 'peak = 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz; under this load the chip holds 2.0-2.2 GHz (tools/probe/conv_timing), i.e. 131-144 TFLOP/s',
                          'flops_per_step': train_fl * BATCH, 'kernel_ms_per_step': conv_s * 1e3,
                          'by_entry_ms': {k: round(v[0] * 1e3, 3) for k, v in per.items()}},

@@ -112,8 +112,11 @@ int y3_conv2d_dgrad_bn_tiles(const y3_tensor* ddst, int ksize, int stride, const
 
 /*
  * Gradient w.r.t. the kernel:  dw[tap][ci][co] = sum_pixels src*ddst.
- * The pixel axis is split over workgroups; the last split of a (k-tile, n-tile) to finish sums the partial slabs in
- * split order inside the kernel.  workspace: y3_conv2d_wgrad_workspace() bytes, zeroed once (contract above).
+ * The pixel axis is split over workgroups.  With 2..8 splits the last split of a (k-tile, n-tile) to finish sums the
+ * partial slabs in split order inside the kernel (tickets); with more splits (layers whose kernel matrix is small and
+ * whose pixel count is large) every split writes a natural-layout slab and slab_reduce_kernel follows in the same call.
+ * Either way the sum order is fixed (bit-reproducible).  workspace: y3_conv2d_wgrad_workspace() bytes, zeroed once
+ * (contract above).
  */
 int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride,
                     float* dw, void* workspace, size_t workspace_bytes, y3_stream_t stream);
