@@ -1410,7 +1410,8 @@ static ConvPlan plan_conv(int M, int Nout, int K, bool fast_ok) {
     static const int rsplit_on = env_int("Y3_RSPLIT", 1);
     // measured (tools/fixed_cost.py, layer_times.py): a 676-tile launch (2.6 workgroups per CU) is better left whole unless
     // K is long; at <= 512 tiles the extra workgroups win over the slab round trip
-    const bool few_tiles = tiles <= 512 || ((long long)tiles * 2 <= want && K >= 2048);
+    static const int few_max = env_int("Y3_FEWTILES", 512);
+    const bool few_tiles = tiles <= few_max || ((long long)tiles * 2 <= want && K >= 2048);
     if (fast_ok && tiles <= Y3_MAX_TICKETS && few_tiles && K >= 2 * min_k) {
         int ks = (int)((want + tiles / 2) / tiles);
         const int maxs = K / min_k;

@@ -183,6 +183,49 @@ def test_conv_fwd_bf16(hip, case):
     assert torch.isnan(dbuf.view(-1, dld)[:, cout:].float()).all(), 'pitch padding overwritten'
 
 
+def test_conv_bf16_pingpong_kernel_is_race_free_at_benchmark_shape(hip):
+    """conv_bf16_pp_kernel at a shape of the tiled path (8 x 76 x 76, 128 -> 256, 3x3: 181 workgroups, 18 K tiles): 40
+    launches must give the same bits (its LDS-DMA ring is ordered only by counted vmcnt waits and barriers: a read placed a
+    phase too early would return stale LDS bytes whenever the DMA happens to land late), and those bits must agree with the
+    fp32 MFMA kernel run on the same bf16-representable operands (exact products; fp32 accumulation order + one bf16
+    rounding: half an ulp + 2e-5 of scale)."""
+    from util import stream
+    n, h, w, cin, cout, k = 8, 76, 76, 128, 256, 3
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16)
+    wk = (torch.randn(k, k, cin, cout, generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(cout, generator=g)
+    xd = x.cuda().contiguous()
+    wf = wk.float().contiguous().cuda()
+    wt = torch.empty(k * k * cout * cin, device='cuda')
+    hip.check(hip.lib.y3_transpose_weights(wf.data_ptr(), wt.data_ptr(), k * k, cin, cout, stream()))
+    wtb = torch.empty(k * k * cout * cin, dtype=torch.bfloat16, device='cuda')
+    hip.check(hip.lib.y3_f32_to_bf16(wt.data_ptr(), wtb.data_ptr(), wt.numel(), stream()))
+    bd = b.cuda()
+    src = hip.Tensor(xd.data_ptr(), n, h, w, cin, cin)
+    outs = []
+    y = torch.empty(n, h, w, cout, dtype=torch.bfloat16, device='cuda')
+    for rep in range(40):
+        y.fill_(float('nan'))
+        hip.check(hip.lib.y3_conv2d_fwd_bf16(src, wtb.data_ptr(), bd.data_ptr(), k, 1, hip.Tensor(y.data_ptr(), n, h, w, cout, cout), 0,
+                                             hip.EPI_LRELU, 0.2, None, None, None, stream()))
+        if rep == 0:
+            first = y.clone()
+        else:
+            assert torch.equal(y.view(torch.int16), first.view(torch.int16)), 'launch %d differs from launch 0' % rep
+    # fp32 MFMA kernel on the same operands
+    x32 = xd.float().contiguous()
+    y32 = torch.empty(n, h, w, cout, device='cuda')
+    wsb = int(hip.lib.y3_conv2d_fwd_workspace(n * h * w, cin, k, cout))
+    ws = torch.zeros(wsb // 4 + 4, device='cuda')
+    hip.check(hip.lib.y3_conv2d_fwd(hip.Tensor(x32.data_ptr(), n, h, w, cin, cin), wf.data_ptr(), bd.data_ptr(), k, 1,
+                                    hip.Tensor(y32.data_ptr(), n, h, w, cout, cout), hip.EPI_LRELU, 0.2, None, None, None, None, ws.data_ptr(), wsb, stream()))
+    ref, got = y32.double(), first.double()
+    scale = float(ref.abs().max())
+    bound = ref.abs() * 2.0 ** -8 + 2e-5 * scale
+    assert bool(torch.isfinite(got).all()) and bool(((got - ref).abs() <= bound).all()), 'max excess %.3e' % float(((got - ref).abs() - bound).max())
+
+
 def test_conv_first_bf16(hip):
     """y3_conv2d_first_bf16 (direct fp32 convolution of the RGB layer, bf16 store) vs fp64: half a bf16 ulp + 1e-5 of scale."""
     from util import nhwc_buf, stream
