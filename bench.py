@@ -286,7 +286,9 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('--gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     ndev = torch.cuda.device_count()               # counting devices does not initialise the GPU
-    if world > 1 and args.backend == 'nccl' and ndev < int(os.environ.get('LOCAL_WORLD_SIZE', str(world))):
+    isolated = any(os.environ.get(k) for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'))
+    if world > 1 and args.backend == 'nccl' and ndev < int(os.environ.get('LOCAL_WORLD_SIZE', str(world))) and not (isolated and ndev >= 1):
+        # (a launcher that hands every rank its own device through *_VISIBLE_DEVICES shows one device per rank: that is fine)
         raise SystemExit('backend nccl (= RCCL) needs one GPU per rank: %d visible, %d ranks (use --backend gloo to rehearse on fewer GPUs)' % (ndev, world))
     torch.cuda.set_device(local_rank % max(1, ndev))
     import torch.distributed as dist

@@ -100,9 +100,10 @@ def train_model(batch_size, test_every_n_steps, train_database_filepath, test_da
         if world > 1:
             os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
             if backend == 'nccl':                  # = RCCL over xGMI, one GPU per rank
-                if torch.cuda.device_count() < int(os.environ.get('LOCAL_WORLD_SIZE', str(world))):
+                isolated = any(os.environ.get(k) for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'))
+                if torch.cuda.device_count() < int(os.environ.get('LOCAL_WORLD_SIZE', str(world))) and not isolated:
                     raise RuntimeError('backend nccl (RCCL) needs one GPU per rank; use --backend gloo to rehearse on fewer')
-                dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank % torch.cuda.device_count()))
             else:
                 dist.init_process_group(backend)
             from yolo3.parallel import DataParallel
