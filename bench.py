@@ -41,7 +41,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mf
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (not the 2:1 sparsity figure)
 
 
-def tiled_4k(use_graph):
+def tiled_4k(use_graph, precisions=('bf16', 'fp32')):
     """BASELINE.json configs[4]: inference_tiled on one synthetic 4096 x 4096 x 3 uint8 image (SURVEY 8d seed 4), 608 x 608
     tiles (100 of them, 96-px ghost border), random-init weights: upload -> GPU tiling + per-tile z-score -> network in
     batches of 25 -> decode -> GPU NMS -> host merge.  Times the whole function per image, fp32 and bf16 conv paths."""
@@ -55,7 +55,7 @@ def tiled_4k(use_graph):
     tb = int(os.environ.get('Y3_TILED_BATCH', '0')) or None      # experiments: fixed tiles per launch instead of the planned batches
     out = {'image': [4096, 4096, 3], 'tile': [608, 608], 'tiles': 100,
            'batches': {'bf16': inference_tiled.plan_tile_batches(100, [608, 608]), 'fp32': [25, 25, 25, 25]}}
-    for prec in ('bf16', 'fp32'):      # bf16 first: its buffers then come out of untouched GPU memory (measured: the figure is bimodal, 30 / 38 ms, with the memory the allocator hands out)
+    for prec in precisions:      # bf16 first: its buffers then come out of untouched GPU memory (measured: the figure is bimodal, 30 / 38 ms, with the memory the allocator hands out)
         y.inference_precision = prec
         mdl = y.get_keras_model()
         with contextlib.redirect_stdout(io.StringIO()):
@@ -307,10 +307,12 @@ def main():
             s_.close()
             os.environ.setdefault('RANK', '0')
             os.environ.setdefault('WORLD_SIZE', '1')
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=300)      # a collective that hangs aborts the rank with a message instead of sitting in the driver's limit
         if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank % max(1, ndev)))
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank % max(1, ndev)), timeout=pg_timeout)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=pg_timeout)
         from yolo3.parallel import DataParallel
         strategy = DataParallel(bucket_mb=args.bucket_mb, force_collective=args.force_collective, transport=args.transport)
 
@@ -469,6 +471,14 @@ def main():
                 raise SystemExit('tiled 4k measurement failed (rc %d): %s' % (res.returncode, res.stderr[-400:]))
             tiled = json.loads(lines[-1])
             tiled['process'] = 'own (fresh GPU context)'
+            # ... and once in THIS process, after dropping every plan of the runs above and handing the cached segments back to
+            # the driver (say what the figure depends on): the same code in memory this process has already churned
+            import gc
+            ymodel._plans.clear()
+            del iplan, rows
+            gc.collect()
+            torch.cuda.empty_cache()
+            tiled['bf16_in_bench_process_after_empty_cache'] = tiled_4k(True, precisions=('bf16',))['bf16']
 
     if rank == 0:
         out = {
