@@ -204,6 +204,16 @@ int y3_upsample_sum2x_bwd(const y3_tensor* dout, const y3_tensor* din, y3_stream
 int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, const float* bias, int ksize, int stride,
                        const y3_tensor* dst, int dst_is_f32, unsigned flags, float alpha,
                        const float* scale, const float* shift, const y3_tensor* resid, y3_stream_t stream);
+/* The same with a caller-owned workspace (y3_conv2d_fwd_bf16_workspace(m = N*OH*OW, cin, ksize, cout) bytes; zero it once, the
+ * first 64 KiB are per-tile tickets that every launch leaves at zero; one stream per workspace): the small-M layers
+ * (<= 1 024 tiles of 64 x 64 and >= 32 K steps: the 13x13 / 26x26 / 19x19 grids at batch 8) are then split along K into up to 8
+ * slices whose fp32 partial sums the last-arriving slice adds in slice order inside the kernel (bit-reproducible).  Without a
+ * workspace (or with y3_conv2d_fwd_bf16) every tile walks its whole K. */
+size_t y3_conv2d_fwd_bf16_workspace(int m, int cin, int ksize, int cout);
+int y3_conv2d_fwd_bf16_ws(const y3_tensor* src, const void* wt_t_bf16, const float* bias, int ksize, int stride,
+                          const y3_tensor* dst, int dst_is_f32, unsigned flags, float alpha,
+                          const float* scale, const float* shift, const y3_tensor* resid,
+                          void* workspace, size_t workspace_bytes, y3_stream_t stream);
 /* The first (RGB) conv_layer straight to bf16: src fp32 NHWC with Cin padded to 4, wt the fp32 Keras kernel
  * [3][3][4][32], 3x3 stride 1 SAME, dst bf16 with 32 channels; same epilogue order as above.  Direct convolution on the
  * vector ALU (K = 36 is too short for MFMA; the layer is a write stream). */

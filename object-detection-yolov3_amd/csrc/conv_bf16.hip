@@ -39,6 +39,13 @@ struct Bf16Args {
     int nbn, out_f32, vec_ok;
     int ohw;
     Y3Div dv_nbn, dv_ohw, dv_ow;   // index decode without run-time divides (y3_make_div)
+    // split-K of the small-M layers (SK instantiations only): block b is slice b % sk_splits of tile b / sk_splits; a slice runs
+    // sk_chunk K steps; partial accumulators go through `slab` (fp32, fragment order) and the slice that draws the tile's last
+    // ticket sums them in slice order and runs the epilogue (same hand-off as conv.hip's fast kernel)
+    int sk_splits, sk_chunk;
+    Y3Div dv_sk;
+    float* slab;
+    int* tickets;
 };
 
 #define Y3_OOB 0x80000000u
@@ -76,7 +83,7 @@ constexpr int stage_rows(int bm, int tm, int cap) {
     return best;
 }
 
-template <int BM, int BN, int WM, int WN, bool STAGED, int BK = 32, int NBUF = 3>
+template <int BM, int BN, int WM, int WN, bool STAGED, int BK = 32, int NBUF = 3, bool SK = false>
 __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128) ? 3 : 1) void conv_bf16_kernel(const Bf16Args p) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int Q = BK / 8;             // 16-byte quads per row and K step (BK = 32: 64-byte rows, 64: 128-byte rows)
@@ -116,7 +123,12 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128) ? 3 : 1) voi
     Y3_PIN_S(nbn); Y3_PIN_S(ohw); Y3_PIN_S(OW); Y3_PIN_S(aM); Y3_PIN_S(aH); Y3_PIN_S(aW); Y3_PIN_S(src_ld); Y3_PIN_S(csh); Y3_PIN_S(csw); Y3_PIN_S(ntaps);
     Y3_PIN_S(dn_m); Y3_PIN_S(dohw_m); Y3_PIN_S(dow_m); Y3_PIN_S(dn_s); Y3_PIN_S(dohw_s); Y3_PIN_S(dow_s);
     const Y3Div dv_nbn = {dn_m, dn_s}, dv_ohw = {dohw_m, dohw_s}, dv_ow = {dow_m, dow_s};
-    const int bid = y3_xcd_remap(blockIdx.x, gridDim.x);
+    const int bid_raw = y3_xcd_remap(blockIdx.x, gridDim.x);
+    int bid = bid_raw, kz = 0;
+    if constexpr (SK) {
+        bid = y3_div(bid_raw, p.dv_sk);
+        kz = bid_raw - bid * p.sk_splits;
+    }
     const int bm = y3_div(bid, dv_nbn), bn = bid - bm * nbn;
     const int m0 = bm * BM, n0 = bn * BN;
 
@@ -193,7 +205,9 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128) ? 3 : 1) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.K / BK;
+    const int nk_all = p.K / BK;
+    const int ks0 = SK ? kz * p.sk_chunk : 0;                                  // first K step of this slice
+    const int nk = SK ? min(p.sk_chunk, nk_all - ks0) : nk_all;               // K steps of this slice (>= 1 by construction)
     auto compute = [&](int buf) {
         const u16* as = smem + buf * STG_U16 + (wm * TM + l31) * LDR;
         const u16* bs = smem + buf * STG_U16 + (BM + wn * TN + l31) * LDR;
@@ -217,22 +231,70 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128) ? 3 : 1) voi
     // The barrier is a raw s_barrier + lgkmcnt(0): __syncthreads() would also drain vmcnt and with it the step in flight.
     constexpr int L = A_LOADS + B_LOADS, AHEAD = NBUF - 1;     // steps in flight
     static_assert(L * (AHEAD - 1) < 16, "vmcnt immediate");
-    const int klast = p.K - BK;
+    const int kfirst = ks0 * BK, klast = (ks0 + nk - 1) * BK;
 #pragma unroll
-    for (int a = 0; a < AHEAD; ++a) glds(min(a * BK, klast), a);
+    for (int a = 0; a < AHEAD; ++a) glds(min(kfirst + a * BK, klast), a);
     Y3_TSTAMP(1);
     int buf = 0, nbuf = AHEAD;
     for (int ks = 0; ks < nk; ++ks) {
         __builtin_amdgcn_s_waitcnt(0x0F70 | (L * (AHEAD - 1)));   // all but the newest AHEAD - 1 steps: this wave's part of step ks is in LDS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's fragment reads of step ks - 1 have returned
         __builtin_amdgcn_s_barrier();                       // ... and so have everybody's: stage (ks - 1) % NBUF is free
-        glds(min((ks + AHEAD) * BK, klast), nbuf);
+        glds(min(kfirst + (ks + AHEAD) * BK, klast), nbuf);
         compute(buf);
         buf = buf == NBUF - 1 ? 0 : buf + 1;
         nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): no DMA may land in the block the epilogue re-uses
     __syncthreads();
+
+    if constexpr (SK) {
+        // park the raw accumulators (slab[tile][slice][r4][thread], 16-byte sc1 stores), take the tile's ticket; the slice that
+        // draws the last one re-reads all slices in slice order (bit-reproducible whichever it is) and goes on to the epilogue
+        constexpr int R4 = MB * NB * 4;
+        const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, 0x7ffffff0, 0x00020000);
+        const unsigned item_bytes = (unsigned)(R4 * THREADS * 16);
+        const unsigned tile0 = (unsigned)(bid * p.sk_splits) * item_bytes + (unsigned)tid * 16u;
+        {
+            const unsigned base = tile0 + (unsigned)kz * item_bytes;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        f32x4 v = {acc[i][j][4 * r], acc[i][j][4 * r + 1], acc[i][j][4 * r + 2], acc[i][j][4 * r + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, base, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
+                    }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(p.tickets + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == p.sk_splits - 1;
+            if (last) __hip_atomic_store(p.tickets + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = last;
+        }
+        __syncthreads();
+        const int last = *flag;
+        __syncthreads();          // smem is the epilogue's staging tile next
+        if (!last) return;
+#pragma unroll 1
+        for (int z = 0; z < p.sk_splits; ++z) {
+            const unsigned base = tile0 + (unsigned)z * item_bytes;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, base, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * r + e] = z == 0 ? v[e] : acc[i][j][4 * r + e] + v[e];
+                    }
+        }
+    }
 
     Y3_TSTAMP(2);
     if constexpr (!STAGED) {
@@ -827,6 +889,17 @@ static int check_bf16_tensor(const y3_tensor* t, const char* name) {
     return 0;
 }
 
+// Experiment switches: read from the environment only in the developer build (make DEV=1); the product library uses the defaults.
+static inline int dev_int(const char* name, int dflt) {
+#ifdef Y3_DEV
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 template <int BM, int BN, int WM, int WN, bool STAGED = true, int BK = 32>
 static void launch_bf16(const Bf16Args& args, int grid, hipStream_t st) {
     Bf16Args p = args;
@@ -834,7 +907,7 @@ static void launch_bf16(const Bf16Args& args, int grid, hipStream_t st) {
     p.dv_nbn = y3_make_div(p.nbn);
     p.dv_ohw = y3_make_div(p.ohw);
     p.dv_ow = y3_make_div(p.OW);
-    static const int nbuf = getenv("Y3_BF16_NBUF") ? atoi(getenv("Y3_BF16_NBUF")) : 3;     // ring depth (experiments): 2, 3 or 4
+    static const int nbuf = dev_int("Y3_BF16_NBUF", 3);     // ring depth (experiments): 2, 3 or 4
     if constexpr (BK == 32 && BM * BN <= 128 * 128) {
         if (nbuf == 4) {
             hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, WM, WN, STAGED, BK, 4>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
@@ -848,9 +921,60 @@ static void launch_bf16(const Bf16Args& args, int grid, hipStream_t st) {
     hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, WM, WN, STAGED, BK, 3>), dim3(grid), dim3(64 * WM * WN), 0, st, p);
 }
 
+// Split-K plan of the 64 x 64-tile path (the small-M layers: 13x13 / 26x26 grids at batch 8, 19x19 at 8 x 608^2): without it a
+// workgroup walks the whole K = 9 Cin (144 steps of 32 at Cin = 512) on its own while most of the chip's wave slots idle.
+#define Y3_BF16_SK_HEADER (64 * 1024)      // tickets: 16 384 tiles
+struct Bf16Split {
+    int splits, chunk;
+    size_t ws_bytes;
+};
+static Bf16Split plan_bf16_split(long long M, int Nout, int K) {
+    Bf16Split s = {1, K / 32, 0};
+    static const int on = dev_int("Y3_BF16_SPLITK", 1);
+    const long long tiles = (long long)y3_cdiv(M, 64) * y3_cdiv(Nout, 64);
+    const int nk = K / 32;
+    static const int maxtiles = dev_int("Y3_BF16_SK_MAXTILES", 512);
+    if (!on || tiles > maxtiles || tiles * 4 > Y3_BF16_SK_HEADER || nk < 32) return s;
+    static const int wgs = dev_int("Y3_BF16_SK_WGS", 1024);
+    static const int minsteps = dev_int("Y3_BF16_SK_MINSTEPS", 16);
+    int want = (int)(wgs / tiles);                     // aim at <= wgs workgroups
+    if (want > 8) want = 8;
+    if (want > nk / minsteps) want = nk / minsteps;    // at least minsteps K steps per slice
+    if (want < 2) return s;
+    s.chunk = y3_cdiv(nk, want);
+    s.splits = y3_cdiv(nk, s.chunk);
+    if (s.splits < 2) {
+        s.splits = 1;
+        s.chunk = nk;
+        return s;
+    }
+    s.ws_bytes = (size_t)Y3_BF16_SK_HEADER + (size_t)tiles * s.splits * 64 * 64 * sizeof(float);
+    return s;
+}
+
+extern "C" size_t y3_conv2d_fwd_bf16_workspace(int m, int cin, int ksize, int cout) {
+    if (cout <= 64) return 0;
+    return plan_bf16_split(m, cout, ksize * ksize * cin).ws_bytes;      // (only consulted when the 64 x 64-tile path is taken)
+}
+
+static int conv2d_fwd_bf16_impl(const y3_tensor* src, const void* wt_t_bf16, const float* bias, int ksize, int stride, const y3_tensor* dst,
+                                int dst_is_f32, unsigned flags, float alpha, const float* scale, const float* shift, const y3_tensor* resid,
+                                void* workspace, size_t workspace_bytes, y3_stream_t stream);
+
 extern "C" int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, const float* bias, int ksize, int stride, const y3_tensor* dst,
                                   int dst_is_f32, unsigned flags, float alpha, const float* scale, const float* shift, const y3_tensor* resid,
                                   y3_stream_t stream) {
+    return conv2d_fwd_bf16_impl(src, wt_t_bf16, bias, ksize, stride, dst, dst_is_f32, flags, alpha, scale, shift, resid, nullptr, 0, stream);
+}
+extern "C" int y3_conv2d_fwd_bf16_ws(const y3_tensor* src, const void* wt_t_bf16, const float* bias, int ksize, int stride, const y3_tensor* dst,
+                                     int dst_is_f32, unsigned flags, float alpha, const float* scale, const float* shift, const y3_tensor* resid,
+                                     void* workspace, size_t workspace_bytes, y3_stream_t stream) {
+    return conv2d_fwd_bf16_impl(src, wt_t_bf16, bias, ksize, stride, dst, dst_is_f32, flags, alpha, scale, shift, resid, workspace, workspace_bytes, stream);
+}
+
+static int conv2d_fwd_bf16_impl(const y3_tensor* src, const void* wt_t_bf16, const float* bias, int ksize, int stride, const y3_tensor* dst,
+                                int dst_is_f32, unsigned flags, float alpha, const float* scale, const float* shift, const y3_tensor* resid,
+                                void* workspace, size_t workspace_bytes, y3_stream_t stream) {
     if (int e = check_bf16_tensor(src, "conv2d_fwd_bf16 src")) return e;
     if (int e = check_bf16_tensor(dst, "conv2d_fwd_bf16 dst")) return e;
     Y3_CHECK_ARG(wt_t_bf16, "conv2d_fwd_bf16: null weights");
@@ -938,11 +1062,11 @@ extern "C" int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, c
     // the matrix pipe, so the best shape follows the grid size: 256x128 tiles (8 waves, K steps of 64) where that gives
     // 150-300 workgroups, 128x128 for larger grids, many small 64x64 workgroups (8+ waves / SIMD) for the small-M layers.
     const bool k64 = p.K % 64 == 0 && (p.ntaps == 1 || p.C % 64 == 0);
-    static const int force = getenv("Y3_BF16_TILE") ? atoi(getenv("Y3_BF16_TILE")) : 0;   // experiments: 1 = 64x64, 2 = 128x128, 3 = 256x128
+    static const int force = dev_int("Y3_BF16_TILE", 0);   // experiments: 1 = 64x64, 2 = 128x128, 3 = 256x128
     const long long t256 = (long long)y3_cdiv(p.M, 256) * y3_cdiv(p.Nout, 128);
     const long long t128 = (long long)y3_cdiv(p.M, 128) * y3_cdiv(p.Nout, 128);
     // the 256 x 256 ping-pong kernel: whole 64-deep K tiles inside one tap, 16-byte rows for the epilogue, Cout in eights
-    static const int pp_mode = getenv("Y3_BF16_PP") ? atoi(getenv("Y3_BF16_PP")) : 1;     // 0 = off (A/B against conv_bf16_kernel)
+    static const int pp_mode = dev_int("Y3_BF16_PP", 1);     // 0 = off (A/B against conv_bf16_kernel)
     const long long tpp = (long long)y3_cdiv(p.M, 256) * y3_cdiv(p.Nout, 256);
     if (pp_mode && p.C % 64 == 0 && p.Nout >= 256 && p.Nout % 8 == 0 && p.vec_ok && tpp >= (pp_mode == 2 ? 1 : 96)) {
         p.nbn = y3_cdiv(p.Nout, 256);
@@ -974,7 +1098,22 @@ extern "C" int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, c
             launch_bf16<128, 128, 2, 2, false>(p, y3_cdiv(p.M, 128) * p.nbn, st);
     } else {
         p.nbn = y3_cdiv(p.Nout, 64);
-        launch_bf16<64, 64, 2, 2>(p, y3_cdiv(p.M, 64) * p.nbn, st);
+        const int tiles = y3_cdiv(p.M, 64) * p.nbn;
+        const Bf16Split sk = plan_bf16_split(p.M, p.Nout, p.K);
+        if (sk.splits > 1 && workspace && workspace_bytes >= sk.ws_bytes) {
+            p.sk_splits = sk.splits;
+            p.sk_chunk = sk.chunk;
+            p.dv_sk = y3_make_div(sk.splits);
+            p.tickets = (int*)workspace;
+            p.slab = (float*)((char*)workspace + Y3_BF16_SK_HEADER);
+            p.ohw = p.OH * p.OW;
+            p.dv_nbn = y3_make_div(p.nbn);
+            p.dv_ohw = y3_make_div(p.ohw);
+            p.dv_ow = y3_make_div(p.OW);
+            hipLaunchKernelGGL((conv_bf16_kernel<64, 64, 2, 2, true, 32, 3, true>), dim3(tiles * sk.splits), dim3(256), 0, st, p);
+        } else {
+            launch_bf16<64, 64, 2, 2>(p, tiles, st);
+        }
     }
     Y3_CHECK_LAUNCH("conv_bf16");
     return Y3_OK;

@@ -65,6 +65,8 @@ SIGNATURES = {
     'y3_upsample_sum2x_bwd': (i32, [TP, TP, vp]),
     'y3_copy': (i32, [TP, TP, vp]),
     'y3_conv2d_fwd_bf16': (i32, [TP, vp, fp, i32, i32, TP, i32, u32, f32, fp, fp, TP, vp]),
+    'y3_conv2d_fwd_bf16_ws': (i32, [TP, vp, fp, i32, i32, TP, i32, u32, f32, fp, fp, TP, vp, sz, vp]),
+    'y3_conv2d_fwd_bf16_workspace': (sz, [i32, i32, i32, i32]),
     'y3_f32_to_bf16': (i32, [fp, vp, sz, vp]),
     'y3_conv2d_first_bf16': (i32, [TP, fp, fp, TP, u32, f32, fp, fp, vp]),
     'y3_tile_gather': (i32, [vp, i32, i32, i32, i32, ip, i32, i32, i32, fp, vp]),

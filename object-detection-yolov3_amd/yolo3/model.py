@@ -284,8 +284,10 @@ class _Plan:
                 self._emit(self.fwd, lib.y3_bn_apply, a.v, scale, shift, resid.v if resid is not None else None, y.v)
                 self.ops.append(('conv_layer', i, src, a, y, resid, (smean, srstd, coef)))
             elif bf and i > 0:
-                self._emit(self.fwd, lib.y3_conv2d_fwd_bf16, src.v, wbf(sp.w_off), ptr(sp.b_off), sp.k, sp.s, y.v, 0, EPI_LRELU, LRELU_ALPHA,
-                           scale, shift, resid.v if resid is not None else None)
+                # (the shared conv workspace: small-M layers are split along K, y3_conv2d_fwd_bf16_workspace)
+                self._conv_call(self.fwd, y.m, sp, lib.y3_conv2d_fwd_bf16_ws, src.v, wbf(sp.w_off), ptr(sp.b_off), sp.k, sp.s, y.v, 0, EPI_LRELU,
+                                LRELU_ALPHA, scale, shift, resid.v if resid is not None else None,
+                                need=int(lib.y3_conv2d_fwd_bf16_workspace(y.m, sp.cin_pad, sp.k, sp.cout)))
             elif bf and sp.cin_pad == 4 and sp.cout == 32 and sp.k == 3 and sp.s == 1:
                 # the RGB layer: fp32 direct convolution, one rounding on the bf16 store
                 self._emit(self.fwd, lib.y3_conv2d_first_bf16, src.v, ptr(sp.w_off), ptr(sp.b_off), y.v, EPI_LRELU, LRELU_ALPHA, scale, shift)
@@ -321,7 +323,8 @@ class _Plan:
             sp = specs[i]
             fm = self._new(N, src.h, src.w, D, Dld, zero=True)
             if bf:      # bf16 operands, fp32 feature map: decode / loss / NMS stay fp32
-                self._emit(self.fwd, lib.y3_conv2d_fwd_bf16, src.v, wbf(sp.w_off), ptr(sp.b_off), 1, 1, fm.v, 1, 0, 0.0, None, None, None)
+                self._conv_call(self.fwd, fm.m, sp, lib.y3_conv2d_fwd_bf16_ws, src.v, wbf(sp.w_off), ptr(sp.b_off), 1, 1, fm.v, 1, 0, 0.0, None, None, None,
+                                need=int(lib.y3_conv2d_fwd_bf16_workspace(fm.m, sp.cin_pad, 1, sp.cout)))
                 return fm
             self._conv_call(self.fwd, fm.m, sp, lib.y3_conv2d_fwd, src.v, ptr(sp.w_off), ptr(sp.b_off), 1, 1, fm.v, 0, 0.0, None, None, None, None)
             self.ops.append(('head', i, src, fm))

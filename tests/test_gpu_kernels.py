@@ -123,6 +123,9 @@ BF16_CASES = [
     (3, 20, 20, 64, 64, 3, 1, True, False),      # BN=64 tile, ragged M
     (1, 13, 13, 512, 1024, 3, 1, True, False),   # long K
     (1, 26, 26, 768, 256, 1, 1, False, False),   # 1x1 with non-power-of-two Cin (route concat)
+    (8, 13, 13, 512, 1024, 3, 1, True, False),   # split-K: 352 tiles x 144 K steps -> 6 slices
+    (2, 19, 19, 256, 512, 3, 2, False, False),   # split-K, stride 2, ragged M (200 rows)
+    (8, 26, 26, 1024, 256, 1, 1, False, True),   # split-K on a 1x1 (32 K steps -> 2 slices), fp32 out
     # the 256 x 256 ping-pong kernel (conv_bf16_pp_kernel: Cin % 64 == 0, Cout >= 256, >= 96 tiles)
     (1, 78, 79, 64, 1024, 1, 1, False, False),   # ONE K tile (+ the all-zero pad tile), ragged M (6162 rows)
     (1, 80, 80, 64, 1024, 3, 1, True, False),    # 3x3 zero padding through the DMA masks, 9 K tiles (odd), residual
@@ -165,10 +168,22 @@ def test_conv_fwd_bf16(hip, case):
     hip.check(hip.lib.y3_f32_to_bf16(wt.data_ptr(), wtb.data_ptr(), wt.numel(), stream()))
     assert torch.equal(wtb.view(k, k, cout, cin).cpu(), wk.permute(0, 1, 3, 2))
     bd, scd, shd = b.cuda(), sc.cuda(), sh.cuda()
-    hip.check(hip.lib.y3_conv2d_fwd_bf16(hip.Tensor(sv.data_ptr(), n, h, w, cin, sld), wtb.data_ptr(), bd.data_ptr(), k, s,
-                                         hip.Tensor(dv.data_ptr(), n, oh, ow, cout, dld), int(out_f32), hip.EPI_LRELU, 0.2,
-                                         scd.data_ptr(), shd.data_ptr(),
-                                         hip.Tensor(rbuf.data_ptr(), n, oh, ow, cout, cout) if with_resid else None, stream()))
+    # through the workspace entry: the small-M cases are then split along K (in-kernel ticketed reduction); run twice on the
+    # same workspace -- the tickets must be left at zero -- and once more without a workspace (whole-K path): same tolerance
+    wsb = int(hip.lib.y3_conv2d_fwd_bf16_workspace(n * oh * ow, cin, k, cout))
+    ws = torch.zeros(wsb // 4 + 4, device='cuda')
+    for rep in range(2):
+        dbuf.fill_(float('nan'))
+        hip.check(hip.lib.y3_conv2d_fwd_bf16_ws(hip.Tensor(sv.data_ptr(), n, h, w, cin, sld), wtb.data_ptr(), bd.data_ptr(), k, s,
+                                                hip.Tensor(dv.data_ptr(), n, oh, ow, cout, dld), int(out_f32), hip.EPI_LRELU, 0.2,
+                                                scd.data_ptr(), shd.data_ptr(),
+                                                hip.Tensor(rbuf.data_ptr(), n, oh, ow, cout, cout) if with_resid else None,
+                                                ws.data_ptr(), wsb, stream()))
+        if rep == 0:
+            first_ws = dbuf.clone()
+    assert torch.equal(torch.nan_to_num(dbuf.float(), nan=-7.0), torch.nan_to_num(first_ws.float(), nan=-7.0)), 'split-K launch not repeatable on one workspace'
+    if wsb:
+        assert int(ws[:16384].view(torch.int32).abs().sum()) == 0, 'tickets not reset'
     ref = F.leaky_relu(_conv_ref(x.float(), wk.float(), b, k, s), 0.2) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
     if with_resid:
         ref = ref + r.double()

@@ -44,7 +44,7 @@ def layer_table(yolo, n, bf16):
     agg, tot = {}, {}
     for i, (nm, args, a, b) in enumerate(recs):
         tot[nm] = tot.get(nm, 0) + best[i]
-        if nm in ('y3_conv2d_fwd', 'y3_conv2d_fwd_bf16'):
+        if nm in ('y3_conv2d_fwd', 'y3_conv2d_fwd_bf16', 'y3_conv2d_fwd_bf16_ws'):
             src, dst, k, s = args[0], args[5], args[3], args[4]
             key = (dst.n * dst.h * dst.w, src.c, dst.c, k, s)
             d = agg.setdefault(key, [0, 0.0])
