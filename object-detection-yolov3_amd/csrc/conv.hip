@@ -461,45 +461,57 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
         b_voff[i] = (idx < B_TOTAL && n < Nout) ? (unsigned)(kr * Nout + n) * 4u : Y3_OOB;
     }
 
-    f32x4 ra[A_LOADS], rb[B_LOADS];
+    // Global -> register -> LDS staging: TWO register sets (tile of K step s lives in set s & 1), so that a tile's loads are
+    // issued two K steps before its LDS stores (one step in the first version: the layers whose launches leave fewer than four
+    // workgroups per CU -- every 1x1 layer -- stood at the stores' vmcnt wait).  8 VGPRs per set on the 64x64 tile.
+    f32x4 ra[2][A_LOADS], rb[2][B_LOADS];
     // Tap -> (source offset, weight row) without a table: indexing the argument-segment tables with a run-time tap is a scalar
     // MEMORY load, and an SMEM load in flight forces every later LDS wait to lgkmcnt(0) (scalar loads return out of order),
     // which stalls the MFMA stream on the fragment reads just issued (a register copy of the tables was turned into a
     // scratch array by the compiler: worse).  Every tap list this kernel sees is a (rows x tg_nx) grid in row-major order
     // (3x3, 1x1, and the 1/2/2/4-tap parity classes of a stride-2 data gradient), so both quantities are affine in the
     // grid coordinates: a few scalar ALU instructions.
+    // K steps at or beyond kend are DEAD (the loop below runs an even number of uniform steps and issues loads three steps ahead):
+    // tap 31 selects a mask bit that is never set and `dead` pushes the weight offsets out of range, so their loads fetch nothing
+    // and return zeros.
     struct Soff {
         int tap, cb, toff, wrow;
+        unsigned dead;
     };
     auto soff_prep = [&](int k0) {
         Soff o;
+        const bool live = k0 < kend;
+        o.dead = live ? 0u : Y3_OOB;
+        k0 = live ? k0 : kbeg;
         o.tap = k0 >> p.logC;  // wave-uniform: scalar unit
         o.cb = k0 & p.cmask;
         const int ty = p.tg_nx == 1 ? o.tap : (p.tg_nx == 2 ? o.tap >> 1 : (o.tap * 11) >> 5);   // tap / tg_nx for tap < 9
         const int tx = o.tap - ty * p.tg_nx;
         o.toff = p.tg_off0 + ty * p.tg_offy + tx * p.tg_offx;
         o.wrow = p.tg_w0 + ty * p.tg_wy + tx * p.tg_wx;
+        o.tap = live ? o.tap : 31;
         return o;
     };
-    auto gload_at = [&](const Soff& o) {
+    auto gload_at = [&](const Soff& o, auto S) {
+        constexpr int set = decltype(S)::value;
         const unsigned a_soff = (unsigned)(o.toff + o.cb * 4);
         const unsigned b_soff = (unsigned)((o.wrow + o.cb) * p.Nout) * 4u;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const unsigned vo = ((a_mask[i] >> o.tap) & 1u) ? a_voff[i] : Y3_OOB;
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, vo, a_soff, 0);
+            ra[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, vo, a_soff, 0);
         }
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[i], b_soff, 0);
+        for (int i = 0; i < B_LOADS; ++i) rb[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[i] | o.dead, b_soff, 0);
     };
-    auto gload = [&](int k0) { gload_at(soff_prep(k0)); };
-    auto lstore = [&](int buf) {
+    auto gload = [&](int k0, auto S) { gload_at(soff_prep(k0), S); };
+    auto lstore = [&](int buf) {     // set 0 -> LDS buffer `buf` (prologue only)
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) *reinterpret_cast<f32x4*>(&As[buf][((tid + i * THREADS) / KV) * LDA + a_kv * 4]) = ra[i];
+        for (int i = 0; i < A_LOADS; ++i) *reinterpret_cast<f32x4*>(&As[buf][((tid + i * THREADS) / KV) * LDA + a_kv * 4]) = ra[0][i];
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const int idx = tid + i * THREADS;
-            if (B_TOTAL % THREADS == 0 || idx < B_TOTAL) *reinterpret_cast<f32x4*>(&Bs[buf][(idx / BN4) * BN + (idx % BN4) * 4]) = rb[i];
+            if (B_TOTAL % THREADS == 0 || idx < B_TOTAL) *reinterpret_cast<f32x4*>(&Bs[buf][(idx / BN4) * BN + (idx % BN4) * 4]) = rb[0][i];
         }
     };
 
@@ -522,9 +534,10 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
         //   group 0 (fragment set 0):  slots carry the LDS reads of set 1 (this step's second half), then the LDS stores of
         //                              the NEXT step's tile (global data loaded one step earlier)
         //   LDS-only barrier            publishes the next buffer; global loads stay in flight across it
-        //   group 1 (fragment set 1):  slots carry the global loads for the step after next, then the LDS reads of the next
-        //                              step's set 0
-        // The last two K steps are peeled, so the steady-state body has no branches.
+        //   group 1 (fragment set 1):  slots carry the global loads for the step THREE ahead (register set (ks + 1) & 1, the one
+        //                              group 0 has just stored from), then the LDS reads of the next step's set 0
+        // The steady-state body is two steps (the register set is a compile-time index) without branches; the last three K steps
+        // run through the peeled forms.
         f32x4 fa[2][MB];
         float fb[2][NB][4];
         constexpr int NM = MB * NB * 4;             // MFMAs per group
@@ -537,9 +550,10 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
         constexpr int NE = MB + 2 + NW;
         Soff nxt;
         int knext = 0;
-        auto event = [&](auto G, auto E, auto H1, auto H2, int cur) {
+        auto event = [&](auto G, auto E, auto H1, auto H2, auto P) {
             constexpr int g = decltype(G)::value, e = decltype(E)::value;
             constexpr bool h1 = decltype(H1)::value, h2 = decltype(H2)::value;
+            constexpr int cur = decltype(P)::value, rs = cur ^ 1;      // LDS buffer of this step; register set stored / reloaded
             if constexpr (g == 0) {
                 // fragment set 1 <- group 1 of the current buffer; then stores of the next tile
                 if constexpr (e < MB) {
@@ -554,11 +568,11 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
                     constexpr int w = e - MB - 2;
                     if (!Y3_ABL(2)) {
                         if constexpr (w < A_LOADS) {
-                            *reinterpret_cast<f32x4*>(&As[cur ^ 1][((tid + w * THREADS) / KV) * LDA + a_kv * 4]) = ra[w];
+                            *reinterpret_cast<f32x4*>(&As[cur ^ 1][((tid + w * THREADS) / KV) * LDA + a_kv * 4]) = ra[rs][w];
                         } else {
                             constexpr int wb = w - A_LOADS;
                             const int idx = tid + wb * THREADS;
-                            if (B_TOTAL % THREADS == 0 || idx < B_TOTAL) *reinterpret_cast<f32x4*>(&Bs[cur ^ 1][(idx / BN4) * BN + (idx % BN4) * 4]) = rb[wb];
+                            if (B_TOTAL % THREADS == 0 || idx < B_TOTAL) *reinterpret_cast<f32x4*>(&Bs[cur ^ 1][(idx / BN4) * BN + (idx % BN4) * 4]) = rb[rs][wb];
                         }
                     }
                 }
@@ -568,9 +582,9 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
                         if (!Y3_ABL(1)) {
                             if constexpr (e < A_LOADS) {
                                 const unsigned vo = ((a_mask[e] >> nxt.tap) & 1u) ? a_voff[e] : Y3_OOB;
-                                ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, vo, (unsigned)(nxt.toff + nxt.cb * 4), 0);
+                                ra[rs][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, vo, (unsigned)(nxt.toff + nxt.cb * 4), 0);
                             } else {
-                                rb[e - A_LOADS] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[e - A_LOADS], (unsigned)((nxt.wrow + nxt.cb) * p.Nout) * 4u, 0);
+                                rb[rs][e - A_LOADS] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[e - A_LOADS] | nxt.dead, (unsigned)((nxt.wrow + nxt.cb) * p.Nout) * 4u, 0);
                             }
                         }
                     }
@@ -589,7 +603,7 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
                 }
             }
         };
-        auto half = [&](auto G, auto H1, auto H2, int cur) {
+        auto half = [&](auto G, auto H1, auto H2, auto P) {
             constexpr int g = decltype(G)::value;
             y3_for_each_ic(std::make_integer_sequence<int, NM>{}, [&](auto M) {
                 constexpr int m = decltype(M)::value;
@@ -598,27 +612,27 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
                 __builtin_amdgcn_sched_barrier(0);
                 // this slot's share of the NE events (spread evenly when there are more events than MFMAs)
                 constexpr int e0 = NE <= NM ? m : m * NE / NM, e1 = NE <= NM ? (m < NE ? m + 1 : m) : (m + 1) * NE / NM;
-                y3_for_each_ic(std::make_integer_sequence<int, e1 - e0>{}, [&](auto D) { event(G, std::integral_constant<int, e0 + decltype(D)::value>{}, H1, H2, cur); });
+                y3_for_each_ic(std::make_integer_sequence<int, e1 - e0>{}, [&](auto D) { event(G, std::integral_constant<int, e0 + decltype(D)::value>{}, H1, H2, P); });
                 // the scalar arithmetic for the NEXT iteration's global-load offsets rides in the slot after this one's loads
-                if constexpr (g == 1 && decltype(H2)::value && m == (NW < NM ? NW : NM - 1)) nxt = soff_prep(min(knext, kend - BK));
+                if constexpr (g == 1 && decltype(H2)::value && m == (NW < NM ? NW : NM - 1)) nxt = soff_prep(knext);
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
-        auto step = [&](auto H1, auto H2, int ks) {
-            const int cur = ks & 1;
-            knext = kbeg + (ks + 3) * BK;
-            half(std::integral_constant<int, 0>{}, H1, H2, cur);
+        auto step = [&](auto H1, auto H2, auto P, int ks) {     // P = ks & 1
+            knext = kbeg + (ks + 4) * BK;
+            half(std::integral_constant<int, 0>{}, H1, H2, P);
             if constexpr (decltype(H1)::value) {
                 if (!Y3_ABL(4)) y3_lds_barrier();
             }
-            half(std::integral_constant<int, 1>{}, H1, H2, cur);
+            half(std::integral_constant<int, 1>{}, H1, H2, P);
         };
-        gload(kbeg);
+        gload(kbeg, std::integral_constant<int, 0>{});
         lstore(0);
         __syncthreads();
         Y3_TSTAMP(1);
-        if (nk > 1) gload(kbeg + BK);
-        nxt = soff_prep(nk > 2 ? kbeg + 2 * BK : kbeg);      // offsets of the loads issued in iteration 0 (K step 2)
+        gload(kbeg + BK, std::integral_constant<int, 1>{});
+        gload(kbeg + 2 * BK, std::integral_constant<int, 0>{});
+        nxt = soff_prep(kbeg + 3 * BK);      // offsets of the loads issued in iteration 0 (K step 3)
         {   // fragment set 0 of step 0
 #pragma unroll
             for (int i = 0; i < MB; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(as_base + i * 32 * LDA);
@@ -627,13 +641,12 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
 #pragma unroll
                 for (int q = 0; q < 4; ++q) fb[0][j][q] = bs_base[q * BN + j * 32];
         }
-        int ks = 0;
-        for (; ks + 2 < nk; ++ks) step(std::true_type{}, std::true_type{}, ks);
-        if (ks + 1 < nk) {
-            step(std::true_type{}, std::false_type{}, ks);
-            ++ks;
+        // Uniform steps, two per iteration: an odd step count is padded with one dead step (all-zero operands), and the stores,
+        // barrier and fragment reads of the last step serve a tile nobody multiplies.
+        for (int ks = 0; ks < nk; ks += 2) {
+            step(std::true_type{}, std::true_type{}, std::integral_constant<int, 0>{}, ks);
+            step(std::true_type{}, std::true_type{}, std::integral_constant<int, 1>{}, ks + 1);
         }
-        step(std::false_type{}, std::false_type{}, ks);
     }
 
     Y3_TSTAMP(2);
@@ -1043,7 +1056,8 @@ __global__ __launch_bounds__(64 * WM * WN, Y3_WGRAD_WAVES_EU) void conv_wgrad_ke
     const int b_pp0 = tid / BN4;
     const unsigned b_lane = (unsigned)(bnn * 4);
 
-    f32x4 ra[A_LOADS], rb[B_LOADS];
+    // two register sets (tile of step s in set s & 1): a tile's loads are issued two steps before its LDS stores (see conv_fast_body)
+    f32x4 ra[2][A_LOADS], rb[2][B_LOADS];
     uint2 pe[A_LOADS];                     // table entries of the step whose loads are issued next
     auto tload = [&](int step) {          // LDS read of the table entries for `step`
 #pragma unroll
@@ -1052,28 +1066,30 @@ __global__ __launch_bounds__(64 * WM * WN, Y3_WGRAD_WAVES_EU) void conv_wgrad_ke
             pe[i] = pix[step * BP + (A_TOTAL % THREADS == 0 || pp < BP ? pp : 0)];
         }
     };
-    auto gload_a = [&](int i) {
+    // `step` may lie beyond the split (the loop pads to an even step count and loads three steps ahead): such loads are
+    // pushed out of range and return zeros
+    auto gload_a = [&](int i, int step, auto S) {
         const int pp = a_pp0 + i * A_PSTEP;
-        const bool ok = ((pe[i].y & a_bit) != 0) & (A_TOTAL % THREADS == 0 || pp < BP);
+        const bool ok = ((pe[i].y & a_bit) != 0) & (A_TOTAL % THREADS == 0 || pp < BP) & (step < nsteps);
         const unsigned off = pe[i].x + (unsigned)a_tapoff;
         const unsigned vo = ok ? off : Y3_OOB;
-        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, vo, 0, 0);
+        ra[decltype(S)::value][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, vo, 0, 0);
     };
-    auto gload_b = [&](int i, int step) {
+    auto gload_b = [&](int i, int step, auto S) {
         const int pp = b_pp0 + i * B_PSTEP;
         const int m = mbeg + step * BP + pp;
         const unsigned off = (unsigned)(m * p.dd_ld) * 4u + b_lane;      // unconditional arithmetic + select: no divergent branch in the loop
         const bool ok = (B_TOTAL % THREADS == 0 || pp < BP) & (m < mend) & bn_ok;
         const unsigned vo = ok ? off : Y3_OOB;
-        rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dd, vo, 0, 0);
+        rb[decltype(S)::value][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dd, vo, 0, 0);
     };
-    auto lstore_a = [&](int i, int buf) {
+    auto lstore_a = [&](int i, int buf, auto S) {
         const int pp = a_pp0 + i * A_PSTEP;
-        if (A_TOTAL % THREADS == 0 || pp < BP) *reinterpret_cast<f32x4*>(&At[buf][pp * BKR + a_kv * 4]) = ra[i];
+        if (A_TOTAL % THREADS == 0 || pp < BP) *reinterpret_cast<f32x4*>(&At[buf][pp * BKR + a_kv * 4]) = ra[decltype(S)::value][i];
     };
-    auto lstore_b = [&](int i, int buf) {
+    auto lstore_b = [&](int i, int buf, auto S) {
         const int pp = b_pp0 + i * B_PSTEP;
-        if (B_TOTAL % THREADS == 0 || pp < BP) *reinterpret_cast<f32x4*>(&Bt[buf][pp * BN + b_n4 * 4]) = rb[i];
+        if (B_TOTAL % THREADS == 0 || pp < BP) *reinterpret_cast<f32x4*>(&Bt[buf][pp * BN + b_n4 * 4]) = rb[decltype(S)::value][i];
     };
 
     f32x16 acc[MB][NB];
@@ -1088,8 +1104,9 @@ __global__ __launch_bounds__(64 * WM * WN, Y3_WGRAD_WAVES_EU) void conv_wgrad_ke
     // pixel pairs; every MFMA is followed by a slot with at most a couple of memory instructions.
     //   group 0: LDS reads of fragment set 1 (pairs 4..7 of this buffer), then the LDS stores of the next step's tile
     //   LDS-only barrier
-    //   group 1: global loads for the step after next (table entries were read a step ahead), the table entries of the step
-    //            after that, then the LDS reads of set 0 from the next buffer
+    //   group 1: global loads for the step THREE ahead into the register set group 0 has just stored from (table entries were
+    //            read a step ahead), the table entries of the step after that, then the LDS reads of set 0 from the next buffer
+    // Uniform steps, two per loop iteration (the register set is a compile-time index); an odd count is padded with a dead step.
     constexpr int GP = 4;
     constexpr int NM = GP * MB * NB;
     constexpr int NW = A_LOADS + B_LOADS;
@@ -1103,37 +1120,34 @@ __global__ __launch_bounds__(64 * WM * WN, Y3_WGRAD_WAVES_EU) void conv_wgrad_ke
 #pragma unroll
         for (int j = 0; j < NB; ++j) fb[set][u][j] = bs_base[buf * (BP * BN) + (g * GP + u) * 2 * BN + j * 32];
     };
-    auto event = [&](auto G, auto E, auto H1, auto H2, int cur, int st) {
+    auto event = [&](auto G, auto E, auto P, int st) {
         constexpr int g = decltype(G)::value, e = decltype(E)::value;
-        constexpr bool h1 = decltype(H1)::value, h2 = decltype(H2)::value;
+        constexpr int cur = decltype(P)::value;
+        constexpr std::integral_constant<int, cur ^ 1> RS{};     // register set stored in group 0 and reloaded in group 1
         if constexpr (g == 0) {
             if constexpr (e < GP) {
                 ldf_pair(cur, 1, e, 1);
             } else if constexpr (e < GP + NW) {
-                if constexpr (h1) {
-                    constexpr int w = e - GP;
-                    if constexpr (w < A_LOADS)
-                        lstore_a(w, cur ^ 1);
-                    else
-                        lstore_b(w - A_LOADS, cur ^ 1);
-                }
+                constexpr int w = e - GP;
+                if constexpr (w < A_LOADS)
+                    lstore_a(w, cur ^ 1, RS);
+                else
+                    lstore_b(w - A_LOADS, cur ^ 1, RS);
             }
         } else {
             if constexpr (e < NW) {
-                if constexpr (h2) {
-                    if constexpr (e < A_LOADS)
-                        gload_a(e);
-                    else
-                        gload_b(e - A_LOADS, st + 2);
-                }
+                if constexpr (e < A_LOADS)
+                    gload_a(e, st + 3, RS);
+                else
+                    gload_b(e - A_LOADS, st + 3, RS);
             } else if constexpr (e == NW) {
-                if constexpr (h2) tload(min(st + 3, nsteps - 1));
-            } else if constexpr (h1) {
+                tload(min(st + 4, nsteps - 1));
+            } else {
                 ldf_pair(cur ^ 1, 0, e - NW - 1, 0);
             }
         }
     };
-    auto half = [&](auto G, auto H1, auto H2, int cur, int st) {
+    auto half = [&](auto G, auto P, int st) {
         constexpr int g = decltype(G)::value;
         y3_for_each_ic(std::make_integer_sequence<int, NM>{}, [&](auto Mi) {
             constexpr int m = decltype(Mi)::value;
@@ -1141,45 +1155,46 @@ __global__ __launch_bounds__(64 * WM * WN, Y3_WGRAD_WAVES_EU) void conv_wgrad_ke
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][u][i], fb[g][u][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             constexpr int e0 = NE <= NM ? m : m * NE / NM, e1 = NE <= NM ? (m < NE ? m + 1 : m) : (m + 1) * NE / NM;
-            y3_for_each_ic(std::make_integer_sequence<int, e1 - e0>{}, [&](auto D) { event(G, std::integral_constant<int, e0 + decltype(D)::value>{}, H1, H2, cur, st); });
+            y3_for_each_ic(std::make_integer_sequence<int, e1 - e0>{}, [&](auto D) { event(G, std::integral_constant<int, e0 + decltype(D)::value>{}, P, st); });
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    auto step = [&](auto H1, auto H2, int st) {
-        const int cur = st & 1;
-        half(std::integral_constant<int, 0>{}, H1, H2, cur, st);
-        if constexpr (decltype(H1)::value) y3_lds_barrier();
-        half(std::integral_constant<int, 1>{}, H1, H2, cur, st);
+    auto step = [&](auto P, int st) {      // P = st & 1
+        half(std::integral_constant<int, 0>{}, P, st);
+        y3_lds_barrier();
+        half(std::integral_constant<int, 1>{}, P, st);
     };
     __syncthreads();                       // pixel table complete
     if (nsteps > 0) {
+        constexpr std::integral_constant<int, 0> S0{};
+        constexpr std::integral_constant<int, 1> S1{};
         tload(0);
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) gload_a(i);
+        for (int i = 0; i < A_LOADS; ++i) gload_a(i, 0, S0);
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) gload_b(i, 0);
+        for (int i = 0; i < B_LOADS; ++i) gload_b(i, 0, S0);
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) lstore_a(i, 0);
+        for (int i = 0; i < A_LOADS; ++i) lstore_a(i, 0, S0);
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) lstore_b(i, 0);
+        for (int i = 0; i < B_LOADS; ++i) lstore_b(i, 0, S0);
         __syncthreads();
-        if (nsteps > 1) {
-            tload(1);
+        tload(min(1, nsteps - 1));
 #pragma unroll
-            for (int i = 0; i < A_LOADS; ++i) gload_a(i);
+        for (int i = 0; i < A_LOADS; ++i) gload_a(i, 1, S1);
 #pragma unroll
-            for (int i = 0; i < B_LOADS; ++i) gload_b(i, 1);
-        }
+        for (int i = 0; i < B_LOADS; ++i) gload_b(i, 1, S1);
         tload(min(2, nsteps - 1));
 #pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) gload_a(i, 2, S0);
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) gload_b(i, 2, S0);
+        tload(min(3, nsteps - 1));
+#pragma unroll
         for (int u = 0; u < GP; ++u) ldf_pair(0, 0, u, 0);
-        int st = 0;
-        for (; st + 2 < nsteps; ++st) step(std::true_type{}, std::true_type{}, st);
-        if (st + 1 < nsteps) {
-            step(std::true_type{}, std::false_type{}, st);
-            ++st;
+        for (int st = 0; st < nsteps; st += 2) {
+            step(S0, st);
+            step(S1, st + 1);
         }
-        step(std::false_type{}, std::false_type{}, st);
     }
     __syncthreads();                       // (the reduction below reuses At as a flag word)
 
@@ -1394,6 +1409,8 @@ struct ConvPlan {
     int tiles, stats_tiles;
     size_t ws_bytes;
 };
+// The K loop of conv_fast_body runs its steps in pairs (an odd count is padded with a dead step): slices get an even step count.
+static inline int even_steps(int chunk) { return chunk + (chunk & 1); }
 // fast_ok: the launch qualifies for conv_igemm_fast_kernel (the only kernel with split-K)
 static ConvPlan plan_conv(int M, int Nout, int K, bool fast_ok) {
     ConvPlan pl;
@@ -1418,7 +1435,7 @@ static ConvPlan plan_conv(int M, int Nout, int K, bool fast_ok) {
         if (ks > maxs) ks = maxs;
         if (ks > 16) ks = 16;
         if (ks > 1) {
-            pl.chunk0 = y3_cdiv(nk, ks);
+            pl.chunk0 = even_steps(y3_cdiv(nk, ks));
             pl.s0 = y3_cdiv(nk, pl.chunk0);
         }
     } else if (fast_ok && rsplit_on && tiles <= Y3_MAX_TICKETS && tiles > cus && nk >= 8) {
@@ -1437,7 +1454,7 @@ static ConvPlan plan_conv(int M, int Nout, int K, bool fast_ok) {
             }
             if (best > 1) {
                 pl.f = F;
-                pl.chunk1 = y3_cdiv(nk, best);
+                pl.chunk1 = even_steps(y3_cdiv(nk, best));
                 pl.s1 = y3_cdiv(nk, pl.chunk1);
             }
         }
@@ -2045,9 +2062,9 @@ static WgradPlan plan_wgrad(int K, int Nout, int M, int taps) {
     const int maxs = y3_cdiv(M, 128);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
-    if (splits < y3_cdiv(M, Y3_WG_TABLE - 16)) splits = y3_cdiv(M, Y3_WG_TABLE - 16);   // a split's pixels fit the kernel's LDS pixel table
+    if (splits < y3_cdiv(M, Y3_WG_TABLE - 32)) splits = y3_cdiv(M, Y3_WG_TABLE - 32);   // a split's pixels fit the kernel's LDS pixel table
     int chunk = y3_cdiv(M, splits);
-    chunk = y3_cdiv(chunk, 16) * 16;
+    chunk = y3_cdiv(chunk, 32) * 32;                   // an even number of 16-pixel steps (the kernel runs its steps in pairs)
     w.splits = y3_cdiv(M, chunk);
     w.chunk = chunk;
     return w;
