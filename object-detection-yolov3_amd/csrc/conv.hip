@@ -323,7 +323,10 @@ struct FastArgs {
 // stamps of the kernel phases + the CU the workgroup ran on.  Compiled out of the product library.
 #ifdef Y3_TIMING
 __device__ int y3_abl_dev = 0;   // ablation mask for the probe: 1 = no global loads in the K loop, 2 = no LDS stores, 4 = no barrier
-#define Y3_ABL(bit) (y3_abl_dev & (bit))
+// read ONCE per workgroup into an SGPR (Y3_ABL_INIT at the top of the kernel body): read inside the loop, the word was re-fetched
+// after every barrier and the probe timed that
+#define Y3_ABL_INIT() const int y3_abl = __builtin_amdgcn_readfirstlane(y3_abl_dev)
+#define Y3_ABL(bit) (y3_abl & (bit))
 __device__ unsigned long long* y3_timing_buf = nullptr;
 #define Y3_TSTAMP(i)                                                                                                    \
     do {                                                                                                                \
@@ -331,6 +334,7 @@ __device__ unsigned long long* y3_timing_buf = nullptr;
     } while (0)
 #else
 #define Y3_TSTAMP(i)
+#define Y3_ABL_INIT()
 #define Y3_ABL(bit) 0
 #endif
 
@@ -373,6 +377,7 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
     float (*red)[WM][BN] = BNS ? reinterpret_cast<float (*)[WM][BN]>(&As[0][0]) : reinterpret_cast<float (*)[WM][BN]>(&red_own[0][0][0]);
 
     Y3_TSTAMP(0);
+    Y3_ABL_INIT();
 #ifdef Y3_TIMING
     if (y3_timing_buf && threadIdx.x == 0) {
         y3_timing_buf[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
