@@ -215,8 +215,9 @@ int y3_conv2d_fwd_bf16_ws(const y3_tensor* src, const void* wt_t_bf16, const flo
                           const float* scale, const float* shift, const y3_tensor* resid,
                           void* workspace, size_t workspace_bytes, y3_stream_t stream);
 /* The first (RGB) conv_layer straight to bf16: src fp32 NHWC with Cin padded to 4, wt the fp32 Keras kernel
- * [3][3][4][32], 3x3 stride 1 SAME, dst bf16 with 32 channels; same epilogue order as above.  Direct convolution on the
- * vector ALU (K = 36 is too short for MFMA; the layer is a write stream). */
+ * [3][3][4][32], 3x3 stride 1 SAME, dst bf16 with 32 channels; same epilogue order as above.  fp32-accurate: input and
+ * weights are split into three bf16 pieces each and multiplied on the matrix pipe (fp32 accumulation), one rounding on the
+ * store.  Any image size; src rows 16-byte aligned. */
 int y3_conv2d_first_bf16(const y3_tensor* src, const float* wt, const float* bias, const y3_tensor* dst,
                          unsigned flags, float alpha, const float* scale, const float* shift, y3_stream_t stream);
 int y3_f32_to_bf16(const float* src, void* dst, size_t count, y3_stream_t stream); /* round-to-nearest-even */

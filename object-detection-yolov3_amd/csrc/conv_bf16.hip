@@ -748,103 +748,150 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pp_kernel(const Bf16Args p) 
 }
 
 // ---------------------------------------------------------------------------
-// The RGB layer (3x3, stride 1, Cin padded to 4, Cout = 32): K = 36 is far too short for the matrix pipe and the
-// layer is a pure write stream (32 channels out for 4 in), so it is a direct convolution on the vector ALU.  A thread
-// owns 4 consecutive pixels of a row x 8 channels: per input row it loads the 6 float4 pixels its 4 windows cover, and
-// every pair of weights read from LDS (4.5 KB, ds_read_b128 = 4 pairs) feeds 4 packed fp32 FMAs, so the kernel sits on
-// the VALU, not on LDS.  The 4 threads of a pixel write its 64 contiguous bytes of bf16.  fp32 arithmetic throughout,
-// one rounding on the store.  Needs W % 4 == 0 (image sides are multiples of 32).
+// The RGB layer (3x3, stride 1, Cin padded to 4, Cout = 32) on the matrix pipe.  (Rounds 1-2 ran it as a direct fp32 convolution
+// on the vector ALU: 864 FMAs per pixel, 737 us for 45 tiles of 608^2 where the 1.06 GB of output needs 213 us.)  A workgroup walks down a 32-pixel column strip in groups of
+// 4 output rows (one row per wave; the weights are split once per workgroup): the 6 x 34 input pixels of a group are loaded once (fp32, 4 channels = 16 bytes), split into THREE bf16 pieces (8 + 8 + 8
+// mantissa bits: the split is exact) and parked in LDS as [piece][row][pixel][4 channels].  For one kernel row ky the K index
+// is kx * 4 + c (16 deep: kx = 3 is padding, its weights are zero), so the B operand of v_mfma_f32_32x32x16_bf16 -- 8
+// consecutive k of one pixel -- is the 16 contiguous bytes of two neighbouring pixels in LDS, and the weights (A operand:
+// D = [channel][pixel], see conv_bf16_pp_kernel) stay in registers, split the same way.  Of the 9 piece products the 6 with
+// piece indices summing to <= 2 are kept (the dropped ones are below 2^-24 of the product): fp32-accurate like the direct
+// kernel, 18 MFMAs per wave.  Epilogue from registers: bias / leaky-relu / BN affine in fp32, v_permlane32_swap to 8-channel
+// runs, one rounding, 16-byte stores (staging the block through LDS for 1 KB-contiguous stores was not faster: 480 vs 430 us).
 // ---------------------------------------------------------------------------
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void y3_split3(float x, u16& h, u16& m, u16& l) {
+    h = f32_to_bf16(x);
+    const float r1 = x - bf16_to_f32(h);
+    m = f32_to_bf16(r1);
+    l = f32_to_bf16(r1 - bf16_to_f32(m));
+}
 
-__global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float* __restrict__ src, int src_ld, const float* __restrict__ wt,
-                                                              const float* __restrict__ bias, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, u16* __restrict__ dst, int dst_ld, int N, int H,
-                                                              int W, unsigned flags, float alpha, unsigned src_bytes) {
-    __shared__ __attribute__((aligned(16))) float ws[9 * 4 * 32];
-    for (int i = threadIdx.x; i < 9 * 4 * 32; i += 256) ws[i] = wt[i];
-    __syncthreads();
-    const long long nquad = (long long)N * H * (W >> 2);
-    const long long quad = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
-    if (quad >= nquad) return;
-    const int cg = (threadIdx.x & 3) * 8;
-    const int wq = W >> 2;
-    const long long rowi = quad / wq;               // n * H + oh
-    const int ow0 = (int)(quad - rowi * wq) * 4;
-    const int oh = (int)(rowi % H);
-    f32x2 acc[4][4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[p][c] = f32x2{0.f, 0.f};
-    // Pixel loads through a buffer descriptor: out-of-image pixels point past num_records and come back as zeros, so the six
-    // loads of a row are branch-free and in flight together (the predicated `cond ? *p : 0` form compiled to a branch and a
-    // full memory wait PER LOAD: 18 serialised round trips per thread, 3x off the VALU bound of this kernel).
+__global__ __launch_bounds__(256) void conv_first_bf16_mfma_kernel(const float* __restrict__ src, int src_ld, const float* __restrict__ wt,
+                                                                   const float* __restrict__ bias, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, u16* __restrict__ dst, int dst_ld, int N,
+                                                                   int H, int W, int xtiles, int rchunks, int groups, unsigned flags,
+                                                                   float alpha, unsigned src_bytes) {
+    __shared__ __attribute__((aligned(16))) u16 tile[2][3][6][36][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int tx = blockIdx.x % xtiles;
+    const int t = blockIdx.x / xtiles;
+    const int rc = t % rchunks, n = t / rchunks;
+    const int x0 = tx * 32;
+    const int ybeg = rc * (4 * groups), yend = min(H, ybeg + 4 * groups);      // `groups` row groups (of 4 rows) per workgroup
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
-    // ... and the loads of row kh + 1 are issued before row kh is multiplied (one loop body, two row buffers).
-    auto load_row = [&](f32x4 (&r)[6], int kh) {
-        const int ih = oh + kh - 1;
-        const bool rok = kh < 3 && (unsigned)ih < (unsigned)H;       // kh = 3: the prefetch of the last iteration fetches nothing
-        const unsigned row_off = (unsigned)((rowi + (kh - 1)) * (long long)W * src_ld * 4);
+    // input staging: thread tid < 204 owns pixel (row tid / 34, column tid % 34) of the 6 x 34 window of every row group
+    const int lr = tid / 34, lp = tid - lr * 34;
+    const bool loader = tid < 6 * 34;
+    const int ix = x0 - 1 + lp;
+    auto gload = [&](int y0) {
+        const int iy = y0 - 1 + lr;
+        const bool ok = loader && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const unsigned off = (unsigned)((((long long)n * H + iy) * W + ix) * src_ld * 4);
+        return __builtin_amdgcn_raw_buffer_load_b128(rs_src, ok ? off : Y3_OOB, 0, 0);
+    };
+    auto lstore = [&](const f32x4& v, int buf) {
+        if (loader) {
+            u16 hh[4], mm[4], ll[4];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int iw = ow0 - 1 + i;
-            r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, (rok && (unsigned)iw < (unsigned)W) ? row_off + (unsigned)(iw * src_ld * 4) : Y3_OOB, 0, 0);
+            for (int c = 0; c < 4; ++c) y3_split3(v[c], hh[c], mm[c], ll[c]);
+            *reinterpret_cast<uint2*>(&tile[buf][0][lr][lp][0]) = make_uint2((unsigned)hh[0] | ((unsigned)hh[1] << 16), (unsigned)hh[2] | ((unsigned)hh[3] << 16));
+            *reinterpret_cast<uint2*>(&tile[buf][1][lr][lp][0]) = make_uint2((unsigned)mm[0] | ((unsigned)mm[1] << 16), (unsigned)mm[2] | ((unsigned)mm[3] << 16));
+            *reinterpret_cast<uint2*>(&tile[buf][2][lr][lp][0]) = make_uint2((unsigned)ll[0] | ((unsigned)ll[1] << 16), (unsigned)ll[2] | ((unsigned)ll[3] << 16));
         }
     };
-    f32x4 xn[6], xc[6];
-    load_row(xn, 0);
-#pragma unroll 1
-    for (int kh = 0; kh < 3; ++kh) {
-        float4 x[6];
+    f32x4 nxt = gload(ybeg);
+    if (tid >= 6 * 34 && tid < 6 * 34 + 36) {
+        // pixels 34 and 35 of every row and piece only ever meet zero weights, but 0 x NaN is NaN: clear them once (both buffers)
+        const int i = tid - 6 * 34, pc = i / 12, r = (i % 12) >> 1, px = 34 + (i & 1);
+        *reinterpret_cast<uint2*>(&tile[0][pc][r][px][0]) = make_uint2(0u, 0u);
+        *reinterpret_cast<uint2*>(&tile[1][pc][r][px][0]) = make_uint2(0u, 0u);
+    }
+    // weights: A operand, lane = (channel l31, k block lh): k = kx * 4 + c for kx = 2 lh, 2 lh + 1 (kx = 3: zero)
+    bf16x8 wf[3][3];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            xc[i] = xn[i];
-            x[i] = make_float4(xc[i][0], xc[i][1], xc[i][2], xc[i][3]);
+    for (int ky = 0; ky < 3; ++ky) {
+        union {
+            u16 u[8];
+            bf16x8 v;
+        } ch, cm, cl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kx = 2 * lh + (e >> 2), c = e & 3;
+            const float w = kx < 3 ? wt[((ky * 3 + kx) * 4 + c) * 32 + l31] : 0.f;
+            y3_split3(w, ch.u[e], cm.u[e], cl.u[e]);
         }
-        load_row(xn, kh + 1);
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const float* w = ws + (kh * 3 + kw) * 128 + cg;
-#pragma unroll
-            for (int ci = 0; ci < 4; ++ci) {
-                const f32x4 wa = *reinterpret_cast<const f32x4*>(w + ci * 32);
-                const f32x4 wb = *reinterpret_cast<const f32x4*>(w + ci * 32 + 4);
-                const f32x2 w2[4] = {f32x2{wa[0], wa[1]}, f32x2{wa[2], wa[3]}, f32x2{wb[0], wb[1]}, f32x2{wb[2], wb[3]}};
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const float4 xv = x[p + kw];
-                    const float xs = ci == 0 ? xv.x : ci == 1 ? xv.y : ci == 2 ? xv.z : xv.w;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[p][c] = __builtin_elementwise_fma(f32x2{xs, xs}, w2[c], acc[p][c]);
-                }
-            }
-        }
+        wf[ky][0] = ch.v;
+        wf[ky][1] = cm.v;
+        wf[ky][2] = cl.v;
     }
     const bool lrelu = flags & Y3_EPI_LRELU;
-    float eb[8], es[8], ef[8];
+    f32x4 eb[4], es[4], ef[4];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        eb[c] = bias ? bias[cg + c] : 0.f;
-        es[c] = scale ? scale[cg + c] : 1.f;
-        ef[c] = scale ? shift[cg + c] : 0.f;
+    for (int g = 0; g < 4; ++g) {
+        const int c = 8 * g + 4 * lh;
+        eb[g] = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        es[g] = scale ? *reinterpret_cast<const f32x4*>(scale + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+        ef[g] = scale ? *reinterpret_cast<const f32x4*>(shift + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    u16* out = dst + (rowi * W + ow0) * dst_ld + cg;
+    lstore(nxt, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int y0 = ybeg; y0 < yend; y0 += 4, buf ^= 1) {
+        const bool more = y0 + 4 < yend;
+        if (more) nxt = gload(y0 + 4);          // in flight under this group's MFMAs and stores
+        f32x16 acc, acc1;                          // two chains: a dependent MFMA waits for its predecessor
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        unsigned packed[4];
+        for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float v[2] = {acc[p][c].x, acc[p][c].y};
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                v[e] += eb[c * 2 + e];
-                if (lrelu) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
-                if (scale) v[e] = v[e] * es[c * 2 + e] + ef[c * 2 + e];
+            for (int pc = 2; pc >= 0; --pc) {      // small pieces first
+                union {
+                    uint2 q[2];
+                    bf16x8 v;
+                } b;
+                b.q[0] = *reinterpret_cast<const uint2*>(&tile[buf][pc][wave + ky][l31 + 2 * lh][0]);
+                b.q[1] = *reinterpret_cast<const uint2*>(&tile[buf][pc][wave + ky][l31 + 2 * lh + 1][0]);
+#pragma unroll
+                for (int wp = 2 - pc; wp >= 0; --wp) {
+                    if ((wp + pc + ky) & 1)
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ky][wp], b.v, acc1, 0, 0, 0);
+                    else
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ky][wp], b.v, acc, 0, 0, 0);
+                }
             }
-            packed[c] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
+        // epilogue: acc[r] = channel 8 (r / 4) + 4 lh + r % 4 of pixel (y0 + wave, x0 + l31)
+        const int oy = y0 + wave, ox = x0 + l31;
+        float v[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = acc[4 * g + j] + eb[g][j];
+                if (lrelu) x = x > 0.f ? x : alpha * x;
+                if (scale) x = x * es[g][j] + ef[g][j];
+                v[4 * g + j] = x;
+            }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Y3_SWAP32(v[8 * e + j], v[8 * e + 4 + j]);
+            // lanes < 32 now hold channels 16 e .. + 7 of their pixel, lanes >= 32 channels 16 e + 8 .. + 15
+            if (oy < yend && ox < W) {
+                const float* w = v + 8 * e;
+                unsigned pk[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pk[q] = (unsigned)f32_to_bf16(w[2 * q]) | ((unsigned)f32_to_bf16(w[2 * q + 1]) << 16);
+                *reinterpret_cast<uint4*>(dst + (((long long)n * H + oy) * W + ox) * dst_ld + 16 * e + 8 * lh) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
         }
-        *reinterpret_cast<uint4*>(out + (long long)p * dst_ld) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        if (more) {
+            lstore(nxt, buf ^ 1);               // the other buffer was last read one iteration ago, before the barrier below
+            __syncthreads();
+        }
     }
 }
 
@@ -1126,12 +1173,15 @@ extern "C" int y3_conv2d_first_bf16(const y3_tensor* src, const float* wt, const
     Y3_CHECK_ARG((src->ld & 3) == 0 && ((uintptr_t)src->ptr & 15) == 0 && (dst->ld & 7) == 0 && ((uintptr_t)dst->ptr & 15) == 0,
                  "conv2d_first_bf16: src must be 16-byte aligned per pixel, dst 16-byte aligned");
     Y3_CHECK_ARG(dst->n == src->n && dst->h == src->h && dst->w == src->w, "conv2d_first_bf16: dst geometry");
-    Y3_CHECK_ARG((src->w & 3) == 0, "conv2d_first_bf16: width %d must be a multiple of 4", src->w);
     Y3_CHECK_ARG((scale == nullptr) == (shift == nullptr), "conv2d_first_bf16: scale/shift must both be given");
     const long long npix = (long long)src->n * src->h * src->w;
     Y3_CHECK_ARG(npix * src->ld * 4 < 0x7fffffffLL, "conv2d_first_bf16: input of 2 GiB or more (split the batch)");
-    hipLaunchKernelGGL(conv_first_bf16_kernel, dim3(y3_cdiv(npix / 4, 64)), dim3(256), 0, (hipStream_t)stream, (const float*)src->ptr, src->ld, wt, bias,
-                       scale, shift, (u16*)dst->ptr, dst->ld, src->n, src->h, src->w, flags, alpha, (unsigned)(npix * src->ld * 4));
+    static const int groups = dev_int("Y3_BF16_FIRST_GROUPS", 16);
+    const int xtiles = y3_cdiv(src->w, 32), rchunks = y3_cdiv(src->h, 4 * groups);
+    const long long wgs = (long long)src->n * rchunks * xtiles;
+    Y3_CHECK_ARG(wgs < 0x7fffffffLL, "conv2d_first_bf16: too many tiles");
+    hipLaunchKernelGGL(conv_first_bf16_mfma_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, (const float*)src->ptr, src->ld, wt, bias,
+                       scale, shift, (u16*)dst->ptr, dst->ld, src->n, src->h, src->w, xtiles, rchunks, groups, flags, alpha, (unsigned)(npix * src->ld * 4));
     Y3_CHECK_LAUNCH("conv_first_bf16");
     return Y3_OK;
 }
