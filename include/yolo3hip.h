@@ -302,6 +302,15 @@ size_t y3_zscore_workspace_bytes(int n);
 int y3_tile_gather(const void* img, int dtype, int height, int width, int channels, const int* table_dev,
                    int ntiles, int tile_h, int tile_w, float* out, y3_stream_t stream);
 
+/* The same tiles, z-scored per tile (y3_zscore: whole-tile mean / population std, subtract-only when std <= 1) and written
+ * straight into a network input buffer: out float32 NHWC [ntiles][tile_h][tile_w][channel_pitch] with the channels beyond C
+ * zeroed (the layout y3_nchw_to_nhwc produces for the first conv_layer).  Two passes over the image instead of five over
+ * the tiles; the results are the bits of y3_tile_gather -> y3_zscore -> y3_nchw_to_nhwc.  workspace:
+ * y3_zscore_workspace_bytes(ntiles). */
+int y3_tile_gather_zscore_nhwc(const void* img, int dtype, int height, int width, int channels, const int* table_dev,
+                               int ntiles, int tile_h, int tile_w, float* out, int channel_pitch, void* workspace,
+                               y3_stream_t stream);
+
 /* ---- gradient exchange: tf.distribute.MirroredStrategy's all-reduce (train.py:38-39, model.py:500,510-515) -------
  * One process per GPU; SUM over the replicas (the loss is already divided by the global batch, model.py:492).  RCCL over
  * xGMI underneath (librccl.so is opened on first use).  Rank 0 calls y3_comm_unique_id and hands the 128 bytes to the

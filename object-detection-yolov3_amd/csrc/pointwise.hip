@@ -914,3 +914,118 @@ extern "C" int y3_tile_gather(const void* img, int dtype, int height, int width,
     Y3_CHECK_LAUNCH("tile_gather");
     return Y3_OK;
 }
+
+// ---------------------------------------------------------------------------
+// y3_tile_gather + y3_zscore + y3_nchw_to_nhwc in two passes over the image instead of five over the tiles: statistics of every
+// (reflect-padded) tile straight from the image, then gather + normalise + channel-pad into the network's NHWC input buffer.
+// The statistics walk the tile in the order zscore_partial_kernel walks the gathered tensor ([C][th][tw], same 128 x 256
+// strided partition, same tree), so mean / std -- and with them every output value -- are the bits the three-kernel path gives.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void tile_stats_kernel(const T* __restrict__ img, int W, int C, const int* __restrict__ table, int th, int tw,
+                                                         double* __restrict__ ws) {
+    __shared__ double sm[2][256];
+    const int tile = blockIdx.y;
+    const int* row = table + tile * 6;
+    const int y0 = row[0], ny = row[1], pre_y = row[2], x0 = row[3], nx = row[4], pre_x = row[5];
+    const unsigned plane = (unsigned)th * (unsigned)tw, count = plane * (unsigned)C;
+    double s = 0.0, q = 0.0;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += (unsigned)Y3_ZS_BLOCKS * 256u) {
+        const unsigned c = i / plane, r = i - c * plane;
+        const unsigned y = r / (unsigned)tw, x = r - y * (unsigned)tw;
+        const int sy = y0 + reflect_index((int)y - pre_y, ny), sx = x0 + reflect_index((int)x - pre_x, nx);
+        const double v = (double)(float)img[((size_t)sy * W + sx) * C + c];
+        s += v;
+        q += v * v;
+    }
+    sm[0][threadIdx.x] = s;
+    sm[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            sm[0][threadIdx.x] += sm[0][threadIdx.x + o];
+            sm[1][threadIdx.x] += sm[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        ws[((size_t)tile * Y3_ZS_BLOCKS + blockIdx.x) * 2 + 0] = sm[0][0];
+        ws[((size_t)tile * Y3_ZS_BLOCKS + blockIdx.x) * 2 + 1] = sm[1][0];
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void tile_gather_norm_kernel(const T* __restrict__ img, int W, int C, const int* __restrict__ table, int th, int tw,
+                                                               const double* __restrict__ ws, float* __restrict__ out, int cpitch) {
+    __shared__ float s_mv, s_sd;
+    const int tile = blockIdx.z;
+    if (threadIdx.x == 0) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < Y3_ZS_BLOCKS; ++b) {     // the order of zscore_apply_kernel
+            s += ws[((size_t)tile * Y3_ZS_BLOCKS + b) * 2 + 0];
+            q += ws[((size_t)tile * Y3_ZS_BLOCKS + b) * 2 + 1];
+        }
+        const double count = (double)C * (double)th * (double)tw;
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mv = (float)mean;
+        s_sd = (float)sqrt(var);
+    }
+    __syncthreads();
+    const float mv = s_mv, sd = s_sd;
+    const bool divide = !(sd <= 1.0f);
+    const int* row = table + tile * 6;
+    const int y0 = row[0], ny = row[1], pre_y = row[2], x0 = row[3], nx = row[4], pre_x = row[5];
+    const int y = blockIdx.y;
+    const int sy = y0 + reflect_index(y - pre_y, ny);
+    const T* src = img + (size_t)sy * W * C;
+    float* dst = out + ((size_t)tile * th + y) * tw * cpitch;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < tw; x += gridDim.x * blockDim.x) {
+        const int sx = x0 + reflect_index(x - pre_x, nx);
+        if (cpitch == 4 && C <= 4) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < C; ++c) {
+                const float d = (float)src[(size_t)sx * C + c] - mv;
+                v[c] = divide ? d / sd : d;
+            }
+            *reinterpret_cast<float4*>(dst + (size_t)x * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int c = 0; c < cpitch; ++c) {
+                float d = 0.f;
+                if (c < C) {
+                    d = (float)src[(size_t)sx * C + c] - mv;
+                    d = divide ? d / sd : d;
+                }
+                dst[(size_t)x * cpitch + c] = d;
+            }
+        }
+    }
+}
+extern "C" int y3_tile_gather_zscore_nhwc(const void* img, int dtype, int height, int width, int channels, const int* table_dev, int ntiles,
+                                          int tile_h, int tile_w, float* out, int channel_pitch, void* workspace, y3_stream_t stream) {
+    Y3_CHECK_ARG(img && table_dev && out && workspace, "tile_gather_zscore_nhwc: null pointer");
+    Y3_CHECK_ARG(height > 0 && width > 0 && channels > 0 && ntiles > 0 && tile_h > 0 && tile_w > 0, "tile_gather_zscore_nhwc: bad dims");
+    Y3_CHECK_ARG(channel_pitch >= channels && (channel_pitch & 3) == 0 && ((uintptr_t)out & 15) == 0, "tile_gather_zscore_nhwc: channel pitch %d (multiple of 4, >= %d channels), out 16-byte aligned", channel_pitch, channels);
+    Y3_CHECK_ARG(tile_h <= 65535 && ntiles <= 65535 && (long long)channels * tile_h * tile_w < 0x7fffffffLL, "tile_gather_zscore_nhwc: grid too large");
+    const dim3 sgrid(Y3_ZS_BLOCKS, ntiles), grid(y3_cdiv(tile_w, 256), tile_h, ntiles), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    double* ws = (double*)workspace;
+    switch (dtype) {
+        case 0:
+            hipLaunchKernelGGL(tile_stats_kernel<unsigned char>, sgrid, block, 0, st, (const unsigned char*)img, width, channels, table_dev, tile_h, tile_w, ws);
+            hipLaunchKernelGGL(tile_gather_norm_kernel<unsigned char>, grid, block, 0, st, (const unsigned char*)img, width, channels, table_dev, tile_h, tile_w, ws, out, channel_pitch);
+            break;
+        case 1:
+            hipLaunchKernelGGL(tile_stats_kernel<unsigned short>, sgrid, block, 0, st, (const unsigned short*)img, width, channels, table_dev, tile_h, tile_w, ws);
+            hipLaunchKernelGGL(tile_gather_norm_kernel<unsigned short>, grid, block, 0, st, (const unsigned short*)img, width, channels, table_dev, tile_h, tile_w, ws, out, channel_pitch);
+            break;
+        case 2:
+            hipLaunchKernelGGL(tile_stats_kernel<float>, sgrid, block, 0, st, (const float*)img, width, channels, table_dev, tile_h, tile_w, ws);
+            hipLaunchKernelGGL(tile_gather_norm_kernel<float>, grid, block, 0, st, (const float*)img, width, channels, table_dev, tile_h, tile_w, ws, out, channel_pitch);
+            break;
+        default: Y3_CHECK_ARG(false, "tile_gather_zscore_nhwc: dtype %d (0 = u8, 1 = u16, 2 = f32)", dtype);
+    }
+    Y3_CHECK_LAUNCH("tile_gather_zscore_nhwc");
+    return Y3_OK;
+}
+

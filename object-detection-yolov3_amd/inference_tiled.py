@@ -72,6 +72,7 @@ def tile_table(height, width, tile_size):
     return np.asarray(rows, np.int32), xs, ys
 
 
+_BANDS = os.environ.get('Y3_TILED_BANDS', '1') != '0'      # (development: 0 = the whole image before the first batch)
 _GATHER_DTYPES = {np.dtype(np.uint8): 0, np.dtype(np.uint16): 1, np.dtype(np.float32): 2}
 
 
@@ -169,7 +170,7 @@ def inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size=N
     if img.dtype not in _GATHER_DTYPES:
         img = img.astype(np.float32)
     code = _GATHER_DTYPES[img.dtype]
-    img_dev = torch.from_numpy(img.view(np.int16) if code == 1 else img).cuda()
+    img_host = torch.from_numpy(img.view(np.int16) if code == 1 else img)
     table, xs, ys = tile_table(img_size[0], img_size[1], tile_size)
     table_dev = torch.from_numpy(table).cuda()
     boxes_list, scores_list, class_label_list = [], [], []
@@ -184,18 +185,6 @@ def inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size=N
                 scores_list.append(r[1])
                 class_label_list.append(r[2])
 
-    # Batches alternate between two streams with their own activation buffers (model slots): the kernels of one batch fill
-    # the launch / prologue / epilogue gaps of the other (two concurrent 25-tile bf16 batches: 3 840 tiles/s against 3 240
-    # one after the other).  Everything is queued first; detections are copied back and merged at the end.
-    cur = torch.cuda.current_stream()
-    slots = 2 if getattr(yolo_model, 'supports_slots', False) else 1
-    streams = [torch.cuda.Stream() for _ in range(slots)] if slots > 1 else [cur]
-    for s in streams:
-        s.wait_stream(cur)                                                # the image upload
-        if s is not cur:
-            img_dev.record_stream(s)
-            table_dev.record_stream(s)
-    queued = []
     if batch_size is None:
         bf16 = getattr(getattr(yolo_model, '_y', None), 'inference_precision', 'fp32') == 'bf16'
         sizes = plan_tile_batches(len(xs), tile_size) if bf16 else None
@@ -205,11 +194,38 @@ def inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size=N
     if sizes is None:
         sizes = [min(batch_size, len(xs) - b0) for b0 in range(0, len(xs), batch_size)]
     starts = [sum(sizes[:i]) for i in range(len(sizes))]
+    # Batches alternate between two streams with their own activation buffers (model slots).  Everything is queued first;
+    # detections are copied back and merged at the end.  The image goes up in BANDS: a batch only needs the rows its tiles
+    # cover, so the network starts after the first band (0.45 of a 4096^2 image for the first 45 of 100 tiles) and the other
+    # bands travel on a copy stream while it runs (a 50 MB image takes ~1 ms over PCIe).
+    cur = torch.cuda.current_stream()
+    slots = 2 if getattr(yolo_model, 'supports_slots', False) else 1
+    slots = min(slots, int(os.environ.get('Y3_TILED_SLOTS', slots)))      # (development: 1 = batches one after the other)
+    streams = [torch.cuda.Stream() for _ in range(slots)] if slots > 1 else [cur]
+    copy_stream = torch.cuda.Stream() if len(sizes) > 1 else cur
+    img_dev = torch.empty(img_host.shape, dtype=img_host.dtype, device='cuda')
+    for s in streams + [copy_stream]:
+        if s is not cur:
+            s.wait_stream(cur)                                            # the allocations above
+            img_dev.record_stream(s)
+            table_dev.record_stream(s)
+    queued = []
+    rows_up = 0
+    fused = hasattr(yolo_model, 'run_tiles') and not getattr(yolo_model, '_fm', False) and os.environ.get('Y3_TILED_FUSED', '1') != '0'
     for bi, (b0, nb) in enumerate(zip(starts, sizes)):
+        need = int((table[b0:b0 + nb, 0] + table[b0:b0 + nb, 1]).max()) if bi + 1 < len(sizes) and _BANDS else img_size[0]
+        if need > rows_up:
+            with torch.cuda.stream(copy_stream):
+                img_dev[rows_up:need].copy_(img_host[rows_up:need])      # pageable memory: returns when the band has arrived
+            rows_up = need
         with torch.cuda.stream(streams[bi % slots]):
-            x = tiles_to_device(img_dev, code, img_size, table_dev, b0, nb, tile_size)
-            x = imagereader.zscore_normalize_device(x)                   # per TILE statistics (inference_tiled.py:205, Q12)
-            rows = yolo_model(x, training=False, slot=bi % slots) if slots > 1 else yolo_model(x, training=False)
+            if fused:
+                # tiles -> z-scored network input in two passes over the image, then the network (yolo3.model.YoloV3.predict_tiles)
+                rows = yolo_model.run_tiles(img_dev, code, img_size, table_dev.data_ptr() + 24 * b0, nb, tile_size=tile_size, slot=bi % slots)
+            else:
+                x = tiles_to_device(img_dev, code, img_size, table_dev, b0, nb, tile_size)
+                x = imagereader.zscore_normalize_device(x)               # per TILE statistics (inference_tiled.py:205, Q12)
+                rows = yolo_model(x, training=False, slot=bi % slots) if slots > 1 else yolo_model(x, training=False)
             rows = torch.as_tensor(rows, dtype=torch.float32).cuda().clone()   # the slot's output buffer is reused two batches later
             queued.append((bbox_utils.detect_async(rows, min_roi_size), b0))
     for item in queued:

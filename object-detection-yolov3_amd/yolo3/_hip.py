@@ -70,6 +70,7 @@ SIGNATURES = {
     'y3_f32_to_bf16': (i32, [fp, vp, sz, vp]),
     'y3_conv2d_first_bf16': (i32, [TP, fp, fp, TP, u32, f32, fp, fp, vp]),
     'y3_tile_gather': (i32, [vp, i32, i32, i32, i32, ip, i32, i32, i32, fp, vp]),
+    'y3_tile_gather_zscore_nhwc': (i32, [vp, i32, i32, i32, i32, ip, i32, i32, i32, fp, i32, vp, vp]),
     'y3_upsample_sum2x_fwd_bf16': (i32, [TP, TP, vp]),
     'y3_add_inplace': (i32, [TP, TP, vp]),
     'y3_fill': (i32, [fp, sz, f32, vp]),

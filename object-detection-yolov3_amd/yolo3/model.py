@@ -181,6 +181,8 @@ class _Plan:
         self.tensors = []
         self.graph = None
         self.infer_graph = None
+        self.infer_graph_tiles = None     # forward (without the input transpose) + decode, for predict_tiles
+        self.zs_ws = None
         self._build()
 
     # -- allocation helpers -------------------------------------------------
@@ -235,6 +237,7 @@ class _Plan:
         li = [0]
 
         x0 = self._new(N, H, W, specs[0].cin_pad, zero=True)
+        self.x0 = x0                      # the network's NHWC input (channels padded to 4): predict_tiles writes it directly
         self._emit(self.fwd, lib.y3_nchw_to_nhwc, self.in_nchw.data_ptr(), N, C, H, W, x0.v)
 
         # shared workspaces.  The largest M*Cout of the net is conv1's (full resolution, FILTER_COUNT/32
@@ -599,8 +602,8 @@ class _Plan:
             if rc != 0:
                 check(rc, fn.__name__)
 
-    def run_forward(self, stream):
-        self._run(self.fwd, stream)
+    def run_forward(self, stream, skip_input=False):
+        self._run(self.fwd[1:] if skip_input else self.fwd, stream)      # fwd[0] is the NCHW -> NHWC transpose of the input
 
     def run_decode(self, stream):
         fn, args = self.decode_call
@@ -629,6 +632,10 @@ class _CallableModel:
         if self._fm:
             return self._y.feature_maps(batch, training=training)
         return self._y.predict(batch, slot=slot)
+
+    def run_tiles(self, img_dev, dtype_code, img_shape, table_ptr, count, tile_size=None, slot=0):
+        """inference_tiled's fast path: gather + z-score + forward + decode of `count` tiles (YoloV3.predict_tiles)."""
+        return self._y.predict_tiles(img_dev, dtype_code, img_shape, table_ptr, count, tile_size=tile_size, slot=slot)
 
     @property
     def trainable_weights(self):
@@ -888,6 +895,37 @@ class YoloV3:
         else:
             st = self._stream()
             plan.run_forward(st)
+            plan.run_decode(st)
+        return plan.boxes
+
+    def predict_tiles(self, img_dev, dtype_code, img_shape, table_ptr, count, tile_size=None, precision=None, slot=0):
+        """One batch of inference_tiled: tiles `table_ptr[0:count]` (device rows of tile_table) of the device-resident HWC image
+        -> z-scored NHWC network input in two passes over the image (y3_tile_gather_zscore_nhwc; the same bits as
+        tiles_to_device -> zscore_normalize_device -> the input transpose), then forward + decode.  Returns [count, Nb, 5+K]."""
+        h, w, c = (int(v) for v in img_shape)
+        if c != self.img_size[2] or (tile_size is not None and [int(tile_size[0]), int(tile_size[1])] != self.img_size[:2]):
+            raise ValueError('tiles %s x %d channels do not match the model input (H,W,C)=%s (Q18: fixed at construction)' % (tile_size, c, self.img_size))
+        count = int(count)
+        plan = self._plan(count, False, (precision or self.inference_precision) == 'bf16', slot)
+        st = self._stream()
+        if plan.zs_ws is None:
+            plan.zs_ws = torch.empty(int(lib.y3_zscore_workspace_bytes(count)) // 8 + 1, dtype=torch.float64, device=self.device)
+        check(lib.y3_tile_gather_zscore_nhwc(img_dev.data_ptr(), int(dtype_code), h, w, c, table_ptr, count, self.img_size[0], self.img_size[1],
+                                             plan.x0.buf.data_ptr(), plan.x0.ld, plan.zs_ws.data_ptr(), st), 'y3_tile_gather_zscore_nhwc')
+        if self.use_graph:
+            if plan.infer_graph_tiles is None:
+                plan.run_forward(st, skip_input=True)
+                plan.run_decode(st)
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    st2 = self._stream()
+                    plan.run_forward(st2, skip_input=True)
+                    plan.run_decode(st2)
+                plan.infer_graph_tiles = g
+            plan.infer_graph_tiles.replay()
+        else:
+            plan.run_forward(st, skip_input=True)
             plan.run_decode(st)
         return plan.boxes
 

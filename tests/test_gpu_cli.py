@@ -61,6 +61,36 @@ def test_device_tiler_matches_host_tiler(dtype):
             assert np.array_equal(got, want), (shape, tile, t0)
 
 
+@pytest.mark.parametrize('dtype', [np.uint8, np.uint16, np.float32])
+def test_fused_tile_preprocessing_equals_the_three_steps(dtype):
+    """y3_tile_gather_zscore_nhwc (what inference_tiled feeds the network with) gives the bits of y3_tile_gather ->
+    y3_zscore -> NHWC with the channels padded to 4 (the three steps the host path and the model's input transpose perform),
+    including the subtract-only branch of the z-score (std <= 1) and a grayscale image."""
+    import inference_tiled
+    from yolo3 import imagereader
+    from yolo3._hip import lib, check
+    cases = [((700, 650, 3), [256, 256], 5, 1.0), ((200, 330, 1), [320, 256], 6, 1.0), ((600, 500, 3), [288, 256], 7, 0.004)]
+    for shape, tile, seed, gain in cases:
+        rng = np.random.default_rng(seed)
+        if dtype == np.float32:
+            img = (rng.standard_normal(shape) * 50 * gain).astype(np.float32)
+        else:
+            img = rng.integers(0, max(2, int(np.iinfo(dtype).max * gain)), shape).astype(dtype)
+        table, _, _ = inference_tiled.tile_table(shape[0], shape[1], tile)
+        code = inference_tiled._GATHER_DTYPES[np.dtype(dtype)]
+        img_dev = torch.from_numpy(img.view(np.int16) if code == 1 else img).cuda()
+        table_dev = torch.from_numpy(table).cuda()
+        n, c = len(table), shape[2]
+        assert n > 0
+        want = imagereader.zscore_normalize_device(inference_tiled.tiles_to_device(img_dev, code, shape, table_dev, 0, n, tile))
+        want = torch.nn.functional.pad(want.permute(0, 2, 3, 1), (0, 4 - c)).contiguous()
+        got = torch.full((n, tile[0], tile[1], 4), float('nan'), device='cuda')
+        ws = torch.empty(int(lib.y3_zscore_workspace_bytes(n)) // 8 + 1, dtype=torch.float64, device='cuda')
+        check(lib.y3_tile_gather_zscore_nhwc(img_dev.data_ptr(), code, shape[0], shape[1], c, table_dev.data_ptr(), n, tile[0], tile[1],
+                                             got.data_ptr(), 4, ws.data_ptr(), torch.cuda.current_stream().cuda_stream), 'y3_tile_gather_zscore_nhwc')
+        assert torch.equal(got, want), (shape, tile, dtype)
+
+
 def test_dataset_prefetch_matches_plain_batches(tmp_path):
     """Dataset.batch(n).prefetch(d) (background thread, pinned staging, GPU z-score) yields exactly what the plain batch
     path yields: one in-order reader process, no shuffling; abandoning an iterator stops its producer thread."""

@@ -190,11 +190,18 @@ def test_tiled_4k_bf16_against_fp32():
     p32, p16 = preds['fp32'], preds['bf16']
     # the batches the bf16 path plans for itself (45 + 45 + 10 tiles for this image: whole rounds of 256 workgroups on the
     # 256 x 256-tile kernel) must give the detections of the 4 x 25 split: a tile's result does not depend on its batch
-    cm = Counting(y.get_keras_model())
+    # ... and so must the fused preprocessing (run_tiles: gather + z-score + input layout in two passes over the image), which
+    # the plain callable above does not offer: the runs above took the three-step host path
+    class CountingFused(Counting):
+        def run_tiles(self, img_dev, code, shape, table_ptr, count, tile_size=None, slot=0):
+            self.tiles += count
+            return self.m.run_tiles(img_dev, code, shape, table_ptr, count, tile_size=tile_size, slot=slot)
+
+    cm = CountingFused(y.get_keras_model())
     with contextlib.redirect_stdout(io.StringIO()):
         p_auto = inference_tiled.inference_image_tiled(cm, big, tile, min_roi)
     assert cm.tiles == 100 and inference_tiled.plan_tile_batches(100, tile) == [45, 45, 10]
-    assert np.array_equal(p_auto, p16), 'planned tile batches changed the detections'
+    assert np.array_equal(p_auto, p16), 'planned tile batches / fused preprocessing changed the detections'
     print('merged detections of the whole image: fp32 %d, bf16 %d' % (len(p32), len(p16)))
     for p in (p32, p16):
         assert p.dtype == np.float64 and p.shape[1] == 6
