@@ -860,7 +860,8 @@ __global__ void zscore_apply_kernel(const float* __restrict__ in, float* __restr
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[i] = (src[i] - mv) / sd;
     }
 }
-extern "C" size_t y3_zscore_workspace_bytes(int n) { return (size_t)n * Y3_ZS_BLOCKS * 2 * sizeof(double); }
+// 128 partial pairs per image, and one {mean, std} float pair per image behind them (y3_tile_gather_zscore_nhwc)
+extern "C" size_t y3_zscore_workspace_bytes(int n) { return (size_t)n * Y3_ZS_BLOCKS * 2 * sizeof(double) + (size_t)n * 2 * sizeof(float); }
 extern "C" int y3_zscore(const float* in, float* out, int n, size_t count, void* workspace, y3_stream_t stream) {
     Y3_CHECK_ARG(in && out && workspace && n > 0 && count > 0, "zscore: bad args");
     hipLaunchKernelGGL(zscore_partial_kernel, dim3(Y3_ZS_BLOCKS, n), dim3(256), 0, (hipStream_t)stream, in, count, (double*)workspace);
@@ -918,8 +919,9 @@ extern "C" int y3_tile_gather(const void* img, int dtype, int height, int width,
 // ---------------------------------------------------------------------------
 // y3_tile_gather + y3_zscore + y3_nchw_to_nhwc in two passes over the image instead of five over the tiles: statistics of every
 // (reflect-padded) tile straight from the image, then gather + normalise + channel-pad into the network's NHWC input buffer.
-// The statistics walk the tile in the order zscore_partial_kernel walks the gathered tensor ([C][th][tw], same 128 x 256
-// strided partition, same tree), so mean / std -- and with them every output value -- are the bits the three-kernel path gives.
+// For float images the statistics walk the tile in the order zscore_partial_kernel walks the gathered tensor ([C][th][tw], same
+// 128 x 256 strided partition, same tree); for 8- and 16-bit images the sums are exact whatever the order.  Either way mean / std
+// -- and with them every output value -- are the bits the three-kernel path gives.
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void tile_stats_kernel(const T* __restrict__ img, int W, int C, const int* __restrict__ table, int th, int tw,
@@ -930,13 +932,29 @@ __global__ __launch_bounds__(256) void tile_stats_kernel(const T* __restrict__ i
     const int y0 = row[0], ny = row[1], pre_y = row[2], x0 = row[3], nx = row[4], pre_x = row[5];
     const unsigned plane = (unsigned)th * (unsigned)tw, count = plane * (unsigned)C;
     double s = 0.0, q = 0.0;
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += (unsigned)Y3_ZS_BLOCKS * 256u) {
-        const unsigned c = i / plane, r = i - c * plane;
-        const unsigned y = r / (unsigned)tw, x = r - y * (unsigned)tw;
-        const int sy = y0 + reflect_index((int)y - pre_y, ny), sx = x0 + reflect_index((int)x - pre_x, nx);
-        const double v = (double)(float)img[((size_t)sy * W + sx) * C + c];
-        s += v;
-        q += v * v;
+    if constexpr (sizeof(T) < 4) {
+        // integer pixels: the sums of values and squares are exact in fp64 (< 2^53 for a 16-bit tile of any size the grid allows), so
+        // the order is free: rows by block, pixels by lane, the channels of a pixel together (coalesced reads, no index divisions)
+        for (int y = blockIdx.x; y < th; y += Y3_ZS_BLOCKS) {
+            const T* src = img + (size_t)(y0 + reflect_index(y - pre_y, ny)) * W * C;
+            for (int x = threadIdx.x; x < tw; x += 256) {
+                const T* px = src + (size_t)(x0 + reflect_index(x - pre_x, nx)) * C;
+                for (int c = 0; c < C; ++c) {
+                    const double v = (double)px[c];
+                    s += v;
+                    q += v * v;
+                }
+            }
+        }
+    } else {
+        for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += (unsigned)Y3_ZS_BLOCKS * 256u) {
+            const unsigned c = i / plane, r = i - c * plane;
+            const unsigned y = r / (unsigned)tw, x = r - y * (unsigned)tw;
+            const int sy = y0 + reflect_index((int)y - pre_y, ny), sx = x0 + reflect_index((int)x - pre_x, nx);
+            const double v = (double)(float)img[((size_t)sy * W + sx) * C + c];
+            s += v;
+            q += v * v;
+        }
     }
     sm[0][threadIdx.x] = s;
     sm[1][threadIdx.x] = q;
@@ -953,30 +971,31 @@ __global__ __launch_bounds__(256) void tile_stats_kernel(const T* __restrict__ i
         ws[((size_t)tile * Y3_ZS_BLOCKS + blockIdx.x) * 2 + 1] = sm[1][0];
     }
 }
+// mean / std of every tile from its 128 partial pairs, summed in the order of zscore_apply_kernel: {mean, std} as two floats behind the partials
+__global__ void tile_stats_finalize_kernel(const double* __restrict__ ws, int ntiles, double count, float* __restrict__ mvsd) {
+    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= ntiles) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < Y3_ZS_BLOCKS; ++b) {
+        s += ws[((size_t)tile * Y3_ZS_BLOCKS + b) * 2 + 0];
+        q += ws[((size_t)tile * Y3_ZS_BLOCKS + b) * 2 + 1];
+    }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mvsd[2 * tile] = (float)mean;
+    mvsd[2 * tile + 1] = (float)sqrt(var);
+}
+#define Y3_TG_ROWS 8       // tile rows per workgroup of the gather
 template <typename T>
 __global__ __launch_bounds__(256) void tile_gather_norm_kernel(const T* __restrict__ img, int W, int C, const int* __restrict__ table, int th, int tw,
-                                                               const double* __restrict__ ws, float* __restrict__ out, int cpitch) {
-    __shared__ float s_mv, s_sd;
+                                                               const float* __restrict__ mvsd, float* __restrict__ out, int cpitch) {
     const int tile = blockIdx.z;
-    if (threadIdx.x == 0) {
-        double s = 0.0, q = 0.0;
-        for (int b = 0; b < Y3_ZS_BLOCKS; ++b) {     // the order of zscore_apply_kernel
-            s += ws[((size_t)tile * Y3_ZS_BLOCKS + b) * 2 + 0];
-            q += ws[((size_t)tile * Y3_ZS_BLOCKS + b) * 2 + 1];
-        }
-        const double count = (double)C * (double)th * (double)tw;
-        const double mean = s / count;
-        double var = q / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        s_mv = (float)mean;
-        s_sd = (float)sqrt(var);
-    }
-    __syncthreads();
-    const float mv = s_mv, sd = s_sd;
+    const float mv = mvsd[2 * tile], sd = mvsd[2 * tile + 1];
     const bool divide = !(sd <= 1.0f);
     const int* row = table + tile * 6;
     const int y0 = row[0], ny = row[1], pre_y = row[2], x0 = row[3], nx = row[4], pre_x = row[5];
-    const int y = blockIdx.y;
+    for (int y = blockIdx.y * Y3_TG_ROWS; y < min(th, (int)(blockIdx.y + 1) * Y3_TG_ROWS); ++y) {
     const int sy = y0 + reflect_index(y - pre_y, ny);
     const T* src = img + (size_t)sy * W * C;
     float* dst = out + ((size_t)tile * th + y) * tw * cpitch;
@@ -1000,6 +1019,7 @@ __global__ __launch_bounds__(256) void tile_gather_norm_kernel(const T* __restri
             }
         }
     }
+    }
 }
 extern "C" int y3_tile_gather_zscore_nhwc(const void* img, int dtype, int height, int width, int channels, const int* table_dev, int ntiles,
                                           int tile_h, int tile_w, float* out, int channel_pitch, void* workspace, y3_stream_t stream) {
@@ -1007,21 +1027,27 @@ extern "C" int y3_tile_gather_zscore_nhwc(const void* img, int dtype, int height
     Y3_CHECK_ARG(height > 0 && width > 0 && channels > 0 && ntiles > 0 && tile_h > 0 && tile_w > 0, "tile_gather_zscore_nhwc: bad dims");
     Y3_CHECK_ARG(channel_pitch >= channels && (channel_pitch & 3) == 0 && ((uintptr_t)out & 15) == 0, "tile_gather_zscore_nhwc: channel pitch %d (multiple of 4, >= %d channels), out 16-byte aligned", channel_pitch, channels);
     Y3_CHECK_ARG(tile_h <= 65535 && ntiles <= 65535 && (long long)channels * tile_h * tile_w < 0x7fffffffLL, "tile_gather_zscore_nhwc: grid too large");
-    const dim3 sgrid(Y3_ZS_BLOCKS, ntiles), grid(y3_cdiv(tile_w, 256), tile_h, ntiles), block(256);
+    const dim3 sgrid(Y3_ZS_BLOCKS, ntiles), grid(1, y3_cdiv(tile_h, Y3_TG_ROWS), ntiles), block(256);
     hipStream_t st = (hipStream_t)stream;
     double* ws = (double*)workspace;
+    // {mean, std} of every tile: two floats per tile behind the partials (y3_zscore_workspace_bytes counts them)
+    float* mvsd = (float*)(ws + (size_t)ntiles * Y3_ZS_BLOCKS * 2);
+    const double count = (double)channels * (double)tile_h * (double)tile_w;
     switch (dtype) {
         case 0:
             hipLaunchKernelGGL(tile_stats_kernel<unsigned char>, sgrid, block, 0, st, (const unsigned char*)img, width, channels, table_dev, tile_h, tile_w, ws);
-            hipLaunchKernelGGL(tile_gather_norm_kernel<unsigned char>, grid, block, 0, st, (const unsigned char*)img, width, channels, table_dev, tile_h, tile_w, ws, out, channel_pitch);
+            hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3(y3_cdiv(ntiles, 64)), dim3(64), 0, st, (const double*)ws, ntiles, count, mvsd);
+            hipLaunchKernelGGL(tile_gather_norm_kernel<unsigned char>, grid, block, 0, st, (const unsigned char*)img, width, channels, table_dev, tile_h, tile_w, (const float*)mvsd, out, channel_pitch);
             break;
         case 1:
             hipLaunchKernelGGL(tile_stats_kernel<unsigned short>, sgrid, block, 0, st, (const unsigned short*)img, width, channels, table_dev, tile_h, tile_w, ws);
-            hipLaunchKernelGGL(tile_gather_norm_kernel<unsigned short>, grid, block, 0, st, (const unsigned short*)img, width, channels, table_dev, tile_h, tile_w, ws, out, channel_pitch);
+            hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3(y3_cdiv(ntiles, 64)), dim3(64), 0, st, (const double*)ws, ntiles, count, mvsd);
+            hipLaunchKernelGGL(tile_gather_norm_kernel<unsigned short>, grid, block, 0, st, (const unsigned short*)img, width, channels, table_dev, tile_h, tile_w, (const float*)mvsd, out, channel_pitch);
             break;
         case 2:
             hipLaunchKernelGGL(tile_stats_kernel<float>, sgrid, block, 0, st, (const float*)img, width, channels, table_dev, tile_h, tile_w, ws);
-            hipLaunchKernelGGL(tile_gather_norm_kernel<float>, grid, block, 0, st, (const float*)img, width, channels, table_dev, tile_h, tile_w, ws, out, channel_pitch);
+            hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3(y3_cdiv(ntiles, 64)), dim3(64), 0, st, (const double*)ws, ntiles, count, mvsd);
+            hipLaunchKernelGGL(tile_gather_norm_kernel<float>, grid, block, 0, st, (const float*)img, width, channels, table_dev, tile_h, tile_w, (const float*)mvsd, out, channel_pitch);
             break;
         default: Y3_CHECK_ARG(false, "tile_gather_zscore_nhwc: dtype %d (0 = u8, 1 = u16, 2 = f32)", dtype);
     }
