@@ -76,7 +76,8 @@ int y3_conv2d_fwd(const y3_tensor* src, const float* wt, const float* bias, int 
  * the split (forward / data gradient) or is an error (kernel gradient).  A header that is NOT zero makes the affected
  * tiles keep stale output without any error (no slice draws the last ticket); to find such a caller run with the
  * environment variable Y3_CHECK_TICKETS=1: every ticketed launch then synchronises its stream, reads the header back and
- * fails with Y3_EINVAL / y3_last_error() if a ticket is non-zero (debug aid: it serialises the stream). */
+ * fails with Y3_EINVAL / y3_last_error() if a ticket is non-zero (debug aid: it serialises the stream; launches on a stream
+ * under graph capture are not checked). */
 int y3_conv2d_stats_tiles(int m, int cin, int ksize, int cout);
 size_t y3_conv2d_fwd_workspace(int m, int cin, int ksize, int cout);
 /* Diagnostics (host only, no launch): the plan y3_conv2d_fwd and the stride-1 y3_conv2d_dgrad use for an implicit GEMM of

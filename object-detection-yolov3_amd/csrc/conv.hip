@@ -1483,9 +1483,13 @@ static ConvPlan plan_conv(int M, int Nout, int K, bool fast_ok) {
 static int check_tickets(const char* what, const void* workspace, hipStream_t st) {
     static const int on = getenv("Y3_CHECK_TICKETS") ? atoi(getenv("Y3_CHECK_TICKETS")) : 0;
     if (!on || !workspace) return Y3_OK;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;      // a stream under graph capture cannot be synchronised: no check there
+    if (hipStreamIsCapturing(st, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) return Y3_OK;
+    // read-back on the launch's own stream (pinned buffer, async copy, then synchronise)
+    static int* host = nullptr;
+    if (!host && hipHostMalloc((void**)&host, Y3_WS_HEADER, hipHostMallocDefault) != hipSuccess) host = nullptr;
+    if (!host || hipMemcpyAsync(host, workspace, Y3_WS_HEADER, hipMemcpyDeviceToHost, st) != hipSuccess) return Y3_OK;
     if (hipStreamSynchronize(st) != hipSuccess) return Y3_OK;
-    static int* host = (int*)malloc(Y3_WS_HEADER);
-    if (!host || hipMemcpy(host, workspace, Y3_WS_HEADER, hipMemcpyDeviceToHost) != hipSuccess) return Y3_OK;
     for (int i = 0; i < Y3_MAX_TICKETS; ++i)
         if (host[i] != 0) {
             y3_set_error("%s: ticket %d of the workspace header is %d, not 0: zero the workspace once after allocating it and keep its "

@@ -208,6 +208,9 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossArgs p) {
     if (threadIdx.x < 4) p.partials[blockIdx.x * 4 + threadIdx.x] = sm[threadIdx.x][0] * p.inv_b;
 }
 
+__global__ void loss_clear_kernel(int* present) {
+    if (threadIdx.x < Y3_MAX_ANCHORS) present[threadIdx.x] = 0;
+}
 __global__ void loss_finalize_kernel(const float* partials, int nblocks, float* loss4) {
     if (threadIdx.x < 4) {
         float s = 0.f;
@@ -247,10 +250,10 @@ extern "C" int y3_loss_fwd_bwd(const y3_tensor* fm, const float* gt, const float
     p.gscale = 1.f / ((float)fm->n * global_batch);
     p.present = (int*)workspace;
     p.partials = (float*)workspace + Y3_MAX_ANCHORS;
-    if (hipMemsetAsync(p.present, 0, Y3_MAX_ANCHORS * sizeof(int), st) != hipSuccess) {
-        y3_set_error("loss_fwd_bwd: memset failed");
-        return Y3_ELAUNCH;
-    }
+    // (a kernel, not hipMemsetAsync: as a memset NODE of a captured graph the clear was not reliably ordered against the loss kernels of
+    // the previous scale, which read the same flags -- a replayed training step computed a wrong loss after the GPU had idled)
+    hipLaunchKernelGGL(loss_clear_kernel, dim3(1), dim3(64), 0, st, p.present);
+    Y3_CHECK_LAUNCH("loss_clear");
     const long long total = (long long)p.N * p.G_h * p.G_w * p.A;
     int pb = (int)((total + 255) / 256);
     if (pb > 256) pb = 256;
