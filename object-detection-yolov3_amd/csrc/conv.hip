@@ -284,6 +284,7 @@ struct FastArgs {
     int tap_off[9];   // byte offset of tap t from the pixel base (biased, >= 0)
     int tap_wrow[9];  // weight row of tap t, channel 0
     int tg_nx, tg_off0, tg_offy, tg_offx, tg_w0, tg_wy, tg_wx;   // the same two tables as affine maps of the tap grid (tap = ty * tg_nx + tx)
+    int tg_mul;          // tap / tg_nx = (tap * tg_mul) >> 5 for tap < 9: 32, 16, 11 for tg_nx = 1, 2, 3 (no branch in the K loop)
     int tap_dh[9], tap_dw[9];
     unsigned src_bytes, wt_bytes, dst_bytes, resid_bytes;  // extents for the buffer descriptors
     int ntaps;
@@ -490,7 +491,7 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
         k0 = live ? k0 : kbeg;
         o.tap = k0 >> p.logC;  // wave-uniform: scalar unit
         o.cb = k0 & p.cmask;
-        const int ty = p.tg_nx == 1 ? o.tap : (p.tg_nx == 2 ? o.tap >> 1 : (o.tap * 11) >> 5);   // tap / tg_nx for tap < 9
+        const int ty = (o.tap * p.tg_mul) >> 5;                  // tap / tg_nx for tap < 9
         const int tx = o.tap - ty * p.tg_nx;
         o.toff = p.tg_off0 + ty * p.tg_offy + tx * p.tg_offx;
         o.wrow = p.tg_w0 + ty * p.tg_wy + tx * p.tg_wx;
@@ -1581,6 +1582,7 @@ static bool make_fast(const ConvArgs& a, int ntaps, int bk, FastArgs* f) {
         while (nx < ntaps && dh[nx] == dh[0]) ++nx;
         if (ntaps % nx != 0) return false;
         p.tg_nx = nx;
+        p.tg_mul = nx == 1 ? 32 : (nx == 2 ? 16 : 11);
         p.tg_off0 = p.tap_off[0];
         p.tg_w0 = p.tap_wrow[0];
         p.tg_offx = nx > 1 ? p.tap_off[1] - p.tap_off[0] : 0;
