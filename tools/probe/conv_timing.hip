@@ -47,10 +47,20 @@ int main(int argc, char** argv) {
     const int maxwg = 1 << 16;
     hipMalloc(&dt, (size_t)maxwg * 8 * 8);
     hipMemset(dt, 0, (size_t)maxwg * 8 * 8);
-    hipMemcpyToSymbol(HIP_SYMBOL(y3_timing_buf), &dt, sizeof(dt));
     const int abl = getenv("Y3_ABL") ? atoi(getenv("Y3_ABL")) : 0;     // ablation (results become wrong, timing stays meaningful)
     hipMemcpyToSymbol(HIP_SYMBOL(y3_abl_dev), &abl, sizeof(abl));
     if (abl) printf("ablation mask %d (1 = no global loads in the K loop, 2 = no LDS stores, 4 = no barrier)\n", abl);
+    {   // the whole launch under the ablation, stamps still off (the buffer pointer is set below)
+        for (int i = 0; i < 5; ++i) run();
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int i = 0; i < 20; ++i) run();
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("launch under ablation %d: %.1f us (stamps off)\n", abl, ms * 50.f);
+    }
+    hipMemcpyToSymbol(HIP_SYMBOL(y3_timing_buf), &dt, sizeof(dt));
     run();
     hipDeviceSynchronize();
     std::vector<unsigned long long> t((size_t)maxwg * 8);
