@@ -159,6 +159,21 @@ def plan_tile_batches(n_tiles, tile_size, compute_units=256):
     return out
 
 
+def upload_bands(table, sizes, height):
+    """Rows of the image that must be on the device before batch i of the tile table can be gathered: the cumulative maximum of
+    y0 + ny over the tiles of batches 0..i (tile_table rows are {y0, ny, pre_y, x0, nx, pre_x}: a tile reads only its crop, the
+    reflected border comes from inside it); the last batch completes the image."""
+    out, hi, t0 = [], 0, 0
+    for i, nb in enumerate(sizes):
+        if i + 1 == len(sizes):
+            hi = int(height)
+        elif nb > 0:
+            hi = max(hi, int((table[t0:t0 + nb, 0] + table[t0:t0 + nb, 1]).max()))
+        out.append(hi)
+        t0 += nb
+    return out
+
+
 def inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size=None):
     """inference_tiled.py:185-310.  ``yolo_model(batch, training=False)`` maps CUDA float32 [B,C,h,w] (z-scored) to
     rows [B, Nb, 5+K] (CUDA tensor or ndarray).  batch_size None: BATCH_SIZE tiles per launch on the fp32 path,
@@ -211,9 +226,10 @@ def inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size=N
             table_dev.record_stream(s)
     queued = []
     rows_up = 0
+    bands = upload_bands(table, sizes, img_size[0]) if _BANDS else [img_size[0]] * len(sizes)
     fused = hasattr(yolo_model, 'run_tiles') and not getattr(yolo_model, '_fm', False) and os.environ.get('Y3_TILED_FUSED', '1') != '0'
     for bi, (b0, nb) in enumerate(zip(starts, sizes)):
-        need = int((table[b0:b0 + nb, 0] + table[b0:b0 + nb, 1]).max()) if bi + 1 < len(sizes) and _BANDS else img_size[0]
+        need = bands[bi]
         if need > rows_up:
             with torch.cuda.stream(copy_stream):
                 img_dev[rows_up:need].copy_(img_host[rows_up:need])      # pageable memory: returns when the band has arrived

@@ -298,6 +298,27 @@ def test_ltrbc_writer_and_inverse_format_boxes_match_reference(golden_dir, tmp_p
     assert np.asarray(inv).tolist() == j['inverse']
 
 
+def test_upload_bands_cover_every_batch():
+    """inference_tiled.upload_bands: every tile of batch i lies inside the rows uploaded up to batch i, the bands never shrink, the
+    last one is the whole image (the network of batch 0 starts while the rest of the image is still on its way)."""
+    import inference_tiled as it
+    for (h, w), tile in (((4096, 4096), [608, 608]), ((1300, 1000), [608, 608]), ((700, 5000), [320, 416]), ((500, 400), [608, 608])):
+        table, _, _ = it.tile_table(h, w, tile)
+        n = len(table)
+        for sizes in ([n], it.plan_tile_batches(n, tile), [1] * n, [max(1, n // 3)] * 3 + [n - 3 * max(1, n // 3)] if n >= 3 else [n]):
+            sizes = [s for s in sizes if s > 0]
+            if sum(sizes) != n:
+                continue
+            bands = it.upload_bands(table, sizes, h)
+            assert len(bands) == len(sizes) and bands[-1] == h and all(a <= b for a, b in zip(bands, bands[1:]))
+            t0 = 0
+            for nb, hi in zip(sizes, bands):
+                assert int((table[t0:t0 + nb, 0] + table[t0:t0 + nb, 1]).max()) <= hi <= h
+                t0 += nb
+    table, _, _ = it.tile_table(4096, 4096, [608, 608])
+    assert it.upload_bands(table, [45, 45, 10], 4096)[0] < 4096 * 0.55      # the first 45 of 100 tiles need about half of the rows
+
+
 def test_tile_batch_planner():
     """inference_tiled.plan_tile_batches (host logic of the bf16 tiled path): batches cover every tile once, whole rounds of
     256 workgroups at the 256 x 256-tile stages, small images stay one batch."""
