@@ -121,6 +121,57 @@ def test_two_stream_step_equals_graph_step_at_benchmark_size():
             assert torch.equal(a.adam_m, m.adam_m) and torch.equal(a.adam_v, m.adam_v)
 
 
+def test_tiled_fp32_pipeline_against_the_oracle_chain():
+    """BASELINE.json configs[4] against the ORACLE, end to end (the 4k test below compares two HIP paths with each other): a
+    1000 x 900 x 3 image, 25 tiles of 416 x 416 (96-px ghost border).  HIP: inference_image_tiled (banded upload, fused tile
+    preprocessing, fp32 network, decode, NMS on the GPU, ghost-band merge).  Oracle: the host tiler (pinned by the reference's
+    tiles.json) -> NumPy z-score per tile -> oracle network fp32 -> decode -> oracle NMS -> the same merge / finalize code
+    (pinned by tiled_e2e.npz; inference_tiled.py:185-310).  Boxes must match at IoU >= 0.8, class for class, both ways."""
+    import contextlib
+    import io
+    import inference_tiled
+    from oracle import model as om
+    from oracle import nms as onms
+    from yolo3 import imagereader
+    from yolo3.model import YoloV3
+    tile, min_roi = [416, 416], 32
+    rng = np.random.default_rng(21)
+    yy, xx = np.mgrid[0:1000, 0:900]
+    img = rng.integers(0, 256, (1000, 900, 3)) * 0.5 + 64 + 60 * np.sin(xx / 23.0)[..., None] * np.cos(yy / 31.0)[..., None]
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    tiles, xs, ys = inference_tiled.convert_image_to_tiles(img, tile)
+    assert len(tiles) == 25
+    yolo = YoloV3(len(tiles), [416, 416, 3], K, ANCHORS, seed=1)
+    x = torch.from_numpy(np.stack([t.astype(np.float32).transpose(2, 0, 1) for t in tiles])).cuda()
+    params = sparse_detector(yolo, imagereader.zscore_normalize_device(x), frac=0.03, min_size=min_roi)
+    with contextlib.redirect_stdout(io.StringIO()):
+        got = inference_tiled.inference_image_tiled(yolo.get_keras_model(), img, tile, min_roi)
+    net = om.Net(params, 3, len(ANCHORS), K, dtype=torch.float32)
+    bl, sl, cl = [], [], []
+    for t, tx, ty in zip(tiles, xs, ys):
+        im = t.astype(np.float32)
+        sd = im.std()
+        z = (im - im.mean()) / (sd if sd > 1.0 else 1.0)
+        with torch.no_grad():
+            fms = net.feature_maps(torch.from_numpy(z.transpose(2, 0, 1)[None].astype(np.float32)), training=False)
+            orow = om.decode(fms, (416, 416, 3), ANCHORS, K).numpy()[0]
+        keep = onms.detect_rows(orow, min_roi)
+        if sum(len(k) for k in keep) == 0:
+            continue
+        boxes = np.concatenate([orow[k, 0:4] for k in keep])
+        scores = np.concatenate([np.sqrt(orow[k, 5 + c] * orow[k, 4]) for c, k in enumerate(keep)])
+        labels = np.concatenate([np.full(len(k), c, np.int32) for c, k in enumerate(keep)])
+        r = inference_tiled.merge_tile_detections(boxes, scores, labels, tx, ty, tile, img.shape)
+        if r is not None:
+            bl.append(r[0]); sl.append(r[1]); cl.append(r[2])
+    want = inference_tiled.finalize_predictions(bl, sl, cl, img.shape)
+    assert got.shape[1] == 6 and want.shape[1] == 6 and len(want) >= 15, (got.shape, want.shape)
+    fa = matched_fraction(got[:, 0:4], got[:, 5], want[:, 0:4], want[:, 5])
+    fb = matched_fraction(want[:, 0:4], want[:, 5], got[:, 0:4], got[:, 5])
+    print('tiled fp32 vs oracle chain: %d / %d boxes, matched %.3f / %.3f' % (len(got), len(want), fa, fb))
+    assert fa >= 0.95 and fb >= 0.95, (fa, fb)
+
+
 def test_tiled_4k_bf16_against_fp32():
     """BASELINE.json configs[4]: 4096 x 4096 x 3 uint8 image, 100 tiles of 608 x 608 (96-px ghost border), the real
     network in launches of 25 tiles on two streams, bf16 conv path + fp32 heads / decode / NMS.
