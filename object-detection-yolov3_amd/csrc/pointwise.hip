@@ -996,29 +996,29 @@ __global__ __launch_bounds__(256) void tile_gather_norm_kernel(const T* __restri
     const int* row = table + tile * 6;
     const int y0 = row[0], ny = row[1], pre_y = row[2], x0 = row[3], nx = row[4], pre_x = row[5];
     for (int y = blockIdx.y * Y3_TG_ROWS; y < min(th, (int)(blockIdx.y + 1) * Y3_TG_ROWS); ++y) {
-    const int sy = y0 + reflect_index(y - pre_y, ny);
-    const T* src = img + (size_t)sy * W * C;
-    float* dst = out + ((size_t)tile * th + y) * tw * cpitch;
-    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < tw; x += gridDim.x * blockDim.x) {
-        const int sx = x0 + reflect_index(x - pre_x, nx);
-        if (cpitch == 4 && C <= 4) {
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int c = 0; c < C; ++c) {
-                const float d = (float)src[(size_t)sx * C + c] - mv;
-                v[c] = divide ? d / sd : d;
-            }
-            *reinterpret_cast<float4*>(dst + (size_t)x * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-            for (int c = 0; c < cpitch; ++c) {
-                float d = 0.f;
-                if (c < C) {
-                    d = (float)src[(size_t)sx * C + c] - mv;
-                    d = divide ? d / sd : d;
+        const int sy = y0 + reflect_index(y - pre_y, ny);
+        const T* src = img + (size_t)sy * W * C;
+        float* dst = out + ((size_t)tile * th + y) * tw * cpitch;
+        for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < tw; x += gridDim.x * blockDim.x) {
+            const int sx = x0 + reflect_index(x - pre_x, nx);
+            if (cpitch == 4 && C <= 4) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int c = 0; c < C; ++c) {
+                    const float d = (float)src[(size_t)sx * C + c] - mv;
+                    v[c] = divide ? d / sd : d;
                 }
-                dst[(size_t)x * cpitch + c] = d;
+                *reinterpret_cast<float4*>(dst + (size_t)x * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                for (int c = 0; c < cpitch; ++c) {
+                    float d = 0.f;
+                    if (c < C) {
+                        d = (float)src[(size_t)sx * C + c] - mv;
+                        d = divide ? d / sd : d;
+                    }
+                    dst[(size_t)x * cpitch + c] = d;
+                }
             }
         }
-    }
     }
 }
 extern "C" int y3_tile_gather_zscore_nhwc(const void* img, int dtype, int height, int width, int channels, const int* table_dev, int ntiles,
