@@ -42,6 +42,16 @@ int y3_version(void);
 /* ---- epilogue flags of y3_conv2d_fwd / y3_conv2d_dgrad ------------------ */
 #define Y3_EPI_LRELU 1u  /* v = v > 0 ? v : alpha*v   (tf.nn.leaky_relu, model.py:34) */
 #define Y3_EPI_ACCUM 2u  /* dst += v instead of dst = v */
+/* Arithmetic selector of y3_conv2d_fwd / y3_conv2d_dgrad / y3_conv2d_dgrad_bn (conv_x3.hip).  Without it the contraction runs on
+ * v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain).  With it every operand element is cut into three bf16 pieces that sum to it
+ * exactly (8 + 8 + 8 significant bits, round to nearest), the six piece pairs that carry more than 2^-26 of a product go through
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-class results (not bit-identical to the fmaf chain; tests/test_gpu_kernels.py
+ * bounds the error against fp64 by that of the fp32 instruction) at 2.67x fewer matrix-pipe cycles.  THE WEIGHT OPERAND CHANGES
+ * LAYOUT with the flag: the kernel needs K contiguous per output column, so y3_conv2d_fwd takes [tap][Cout][Cin] (what
+ * y3_transpose_weights writes) and y3_conv2d_dgrad* take [tap][Cin][Cout] (the Keras kernel) -- each entry point the copy the
+ * OTHER one takes without the flag.  Shapes: y3_conv2d_x3_ok(); stride-2 data gradients are not built.  Everything else -- epilogue,
+ * statistics, split-K workspace contract -- is unchanged; ask the *_x queries for tile counts and workspace sizes. */
+#define Y3_CONV_X3 4u
 
 /*
  * Tensor view: NHWC, `ld` floats between consecutive pixels.
@@ -80,6 +90,13 @@ int y3_conv2d_fwd(const y3_tensor* src, const float* wt, const float* bias, int 
  * under graph capture are not checked). */
 int y3_conv2d_stats_tiles(int m, int cin, int ksize, int cout);
 size_t y3_conv2d_fwd_workspace(int m, int cin, int ksize, int cout);
+/* The same two queries for a launch with `flags` (Y3_CONV_X3 changes the tile and the split-K plan). */
+int y3_conv2d_stats_tiles_x(int m, int cin, int ksize, int cout, unsigned flags);
+size_t y3_conv2d_fwd_workspace_x(int m, int cin, int ksize, int cout, unsigned flags);
+/* 1 if the Y3_CONV_X3 kernels take an implicit GEMM of m rows, `ntaps` taps of `c` contracted channels each and `nout` output
+ * columns (forward: c = Cin, nout = Cout; stride-1 data gradient: c = Cout, nout = Cin): c a multiple of 16 (a power of two when
+ * ntaps > 1), nout >= 32. */
+int y3_conv2d_x3_ok(int m, int c, int ntaps, int nout);
 /* Diagnostics (host only, no launch): the plan y3_conv2d_fwd and the stride-1 y3_conv2d_dgrad use for an implicit GEMM of
  * m x cout x (ksize^2 * cin).  out13 = {bm, bn, bk, tiles, f, s0, s1, chunk0, chunk1, grid, stats_tiles, fast, nk}: tiles
  * [0, f) are cut into s0 K slices of chunk0 K steps, tiles [f, tiles) into s1 of chunk1 (nk K steps in all); grid = work
@@ -98,6 +115,7 @@ int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksize, int str
                     const y3_tensor* dsrc, unsigned flags, void* workspace, size_t workspace_bytes,
                     y3_stream_t stream);
 size_t y3_conv2d_dgrad_workspace(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc);
+size_t y3_conv2d_dgrad_workspace_x(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc, unsigned flags);
 /*
  * y3_conv2d_dgrad whose epilogue also sums the six raw moments of (dsrc after this launch, bn_a) per output column and
  * row tile -- the statistics of the BatchNorm backward of the layer that PRODUCED dsrc's activation (bn_a = that layer's
@@ -110,6 +128,7 @@ int y3_conv2d_dgrad_bn(const y3_tensor* ddst, const float* wt_t, int ksize, int 
                        unsigned flags, const y3_tensor* bn_a, float* bn_partials,
                        void* workspace, size_t workspace_bytes, y3_stream_t stream);
 int y3_conv2d_dgrad_bn_tiles(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc);
+int y3_conv2d_dgrad_bn_tiles_x(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc, unsigned flags);
 
 /*
  * Gradient w.r.t. the kernel:  dw[tap][ci][co] = sum_pixels src*ddst.

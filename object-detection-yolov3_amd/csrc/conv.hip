@@ -47,6 +47,7 @@ struct ConvArgs {
     const float* bn_a;   // data gradient with BatchNorm-backward statistics in the epilogue (y3_conv2d_dgrad_bn): the activation `a`
     float* bn_part;      // ... and the partial sums [row tile][6][Nout]
     int bn_a_ld;
+    int x3;              // Y3_CONV_X3: the launch runs conv_x3.hip and `wt` is the copy with K contiguous per output column
 };
 
 template <int BM, int BN, int WM, int WN, int BK>
@@ -265,97 +266,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
     }
 }
 
-// ---------------------------------------------------------------------------
-// Fast path of the same gather-GEMM (taken when C % BK == 0, i.e. every layer except the first conv; the 14-channel
-// heads included -- see make_fast): a K step never straddles a tap, so the tap and the channel
-// base are wave-uniform and travel in the scalar offset of buffer loads; per-lane offsets are loop
-// invariant; padding / tile-edge lanes are pointed past the descriptor's range and read zeros from the
-// hardware bounds check instead of branching.
-// ---------------------------------------------------------------------------
-struct FastArgs {
-    const float* src;  // biased so that every tap offset is >= 0
-    const float* wt;
-    float* dst;
-    const float* bias;
-    const float* scale;
-    const float* shift;
-    const float* resid;
-    float* stats;
-    int tap_off[9];   // byte offset of tap t from the pixel base (biased, >= 0)
-    int tap_wrow[9];  // weight row of tap t, channel 0
-    int tg_nx, tg_off0, tg_offy, tg_offx, tg_w0, tg_wy, tg_wx;   // the same two tables as affine maps of the tap grid (tap = ty * tg_nx + tx)
-    int tg_mul;          // tap / tg_nx = (tap * tg_mul) >> 5 for tap < 9: 32, 16, 11 for tg_nx = 1, 2, 3 (no branch in the K loop)
-    int tap_dh[9], tap_dw[9];
-    unsigned src_bytes, wt_bytes, dst_bytes, resid_bytes;  // extents for the buffer descriptors
-    int ntaps;
-    int H, W, logC, cmask, src_ld;
-    int OH, OW, sh, sw;
-    int DH, DW, dsh, dsw, doh, dow, dst_ld;
-    int resid_ld;
-    int Nout, K, M;
-    unsigned flags;
-    float alpha;
-    int nbn, nbm, col_major;
-    // divisions of the index decode as multiply-high + shift (y3_make_div): tile id by the fastest-varying tile count, work
-    // item by the slice counts, output pixel by OH*OW and by OW
-    int nb_fast, ohw;
-    Y3Div dv_nb, dv_s0, dv_s1, dv_ohw, dv_ow;
-    // Split-K with the reduction inside the kernel.  Work items: tiles [0, sk_f) are cut into sk_s0 K slices each, tiles
-    // [sk_f, tiles) into sk_s1 (the remainder of a launch whose tile count is not a multiple of the CU count is split
-    // finer so that every CU ends up with the same amount of MFMA work).  Item i < sk_n0 = sk_f * sk_s0 is slice
-    // i % sk_s0 of tile i / sk_s0; item i >= sk_n0 is slice (i - sk_n0) % sk_s1 of tile sk_f + (i - sk_n0) / sk_s1.  A slice
-    // covers sk_chunk{0,1} K steps.  Slices of a split tile park their raw accumulators in `slab` (item-major, fragment
-    // order) and take a ticket; the slice that draws the last ticket re-reads ALL of them in slice order (fixed order ->
-    // bit-reproducible), runs the normal epilogue and leaves the ticket at zero for the next launch.
-    int sk_f, sk_n0, sk_s0, sk_s1, sk_chunk0, sk_chunk1;
-    int sk_slab0;        // first item that owns a slab slot (0, or sk_n0 when only the remainder tiles are split)
-    float* slab;
-    int* tickets;        // one per tile, zero before the launch
-    const float* bn_a;   // BNS kernels: activation of the BatchNorm layer whose output gradient this launch completes (dst geometry)
-    float* bn_part;      // BNS kernels: [row tile][6][Nout] partial raw moments of (dst, bn_a), see bn_bwd_stats_kernel
-    unsigned bn_a_bytes;
-    int bn_a_ld;
-    int bn_row0;         // BNS: first partial row of this launch / parity class (rows are bn_row0 + row tile)
-};
-
-#define Y3_OOB 0x80000000u
-
-// Development instrumentation (tools/probe/conv_timing.hip builds this file with -DY3_TIMING): per-workgroup s_memtime
-// stamps of the kernel phases + the CU the workgroup ran on.  Compiled out of the product library.
-#ifdef Y3_TIMING
-__device__ int y3_abl_dev = 0;   // ablation mask for the probe: 1 = no global loads in the K loop, 2 = no LDS stores, 4 = no barrier
-// read ONCE per workgroup into an SGPR (Y3_ABL_INIT at the top of the kernel body): read inside the loop, the word was re-fetched
-// after every barrier and the probe timed that
-#define Y3_ABL_INIT() const int y3_abl = __builtin_amdgcn_readfirstlane(y3_abl_dev)
-#define Y3_ABL(bit) (y3_abl & (bit))
-__device__ unsigned long long* y3_timing_buf = nullptr;
-#define Y3_TSTAMP(i)                                                                                                    \
-    do {                                                                                                                \
-        if (y3_timing_buf && threadIdx.x == 0) y3_timing_buf[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-#else
-#define Y3_TSTAMP(i)
-#define Y3_ABL_INIT()
-#define Y3_ABL(bit) 0
-#endif
-
-template <int... I, class F>
-__device__ __forceinline__ void y3_for_each_ic(std::integer_sequence<int, I...>, F&& f) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-// Instruction-mix directives for the machine scheduler (masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write)
-template <int MASK, int N>
-__device__ __forceinline__ void y3_sgb() {
-    if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
-}
-template <int COUNT, int MASK, int MFMAS = 1>
-__device__ __forceinline__ void y3_sgb_pairs() {   // COUNT x { MFMAS matrix instructions, then one instruction of MASK }
-    if constexpr (COUNT > 0) {
-        y3_sgb<0x008, MFMAS>();
-        y3_sgb<MASK, 1>();
-        y3_sgb_pairs<COUNT - 1, MASK, MFMAS>();
-    }
-}
+#include "conv_fast.h"   // FastArgs, the work-item decode, the split-K hand-off and the epilogue (shared with conv_x3.hip)
 
 template <int BM, int BN, int WM, int WN, int BK, bool DENSE, bool BNS = false>
 __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw, const int grid) {
@@ -386,52 +297,12 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
         y3_timing_buf[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-    // Every scalar of the index decode is fetched from the argument segment HERE, in one batch (the pins keep the compiler from
-    // sinking each load to its first use): left alone it emitted ~17 load / wait / branch rounds of ~200 cycles each before
-    // the first global load of the workgroup was issued.
-    int sk_n0 = p.sk_n0, sk_s0 = p.sk_s0, sk_s1 = p.sk_s1, sk_f = p.sk_f, sk_c0 = p.sk_chunk0, sk_c1 = p.sk_chunk1;
-    int col_major = p.col_major, nb_fast = p.nb_fast, ohw = p.ohw, OW = p.OW, aK = p.K, aM = p.M, aH = p.H, aW = p.W;
-    int src_ld = p.src_ld, csh = p.sh, csw = p.sw, ntaps = p.ntaps, Nout = p.Nout;
-    unsigned dnb_m = p.dv_nb.mul, ds0_m = p.dv_s0.mul, ds1_m = p.dv_s1.mul, dohw_m = p.dv_ohw.mul, dow_m = p.dv_ow.mul;
-    int dnb_s = p.dv_nb.shift, ds0_s = p.dv_s0.shift, ds1_s = p.dv_s1.shift, dohw_s = p.dv_ohw.shift, dow_s = p.dv_ow.shift;
-    Y3_PIN_S(sk_n0); Y3_PIN_S(sk_s0); Y3_PIN_S(sk_s1); Y3_PIN_S(sk_f); Y3_PIN_S(sk_c0); Y3_PIN_S(sk_c1);
-    Y3_PIN_S(col_major); Y3_PIN_S(nb_fast); Y3_PIN_S(ohw); Y3_PIN_S(OW); Y3_PIN_S(aK); Y3_PIN_S(aM); Y3_PIN_S(aH); Y3_PIN_S(aW);
-    Y3_PIN_S(src_ld); Y3_PIN_S(csh); Y3_PIN_S(csw); Y3_PIN_S(ntaps); Y3_PIN_S(Nout);
-    Y3_PIN_S(dnb_m); Y3_PIN_S(ds0_m); Y3_PIN_S(ds1_m); Y3_PIN_S(dohw_m); Y3_PIN_S(dow_m);
-    Y3_PIN_S(dnb_s); Y3_PIN_S(ds0_s); Y3_PIN_S(ds1_s); Y3_PIN_S(dohw_s); Y3_PIN_S(dow_s);
-    const Y3Div dv_nb = {dnb_m, dnb_s}, dv_s0 = {ds0_m, ds0_s}, dv_s1 = {ds1_m, ds1_s}, dv_ohw = {dohw_m, dohw_s}, dv_ow = {dow_m, dow_s};
-
-    // work item: ids are contiguous per XCD inside the two ranges [0, sk_n0) and [sk_n0, grid)
-    const int bid0 = braw < sk_n0 ? y3_xcd_remap(braw, sk_n0) : sk_n0 + y3_xcd_remap(braw - sk_n0, grid - sk_n0);
-    int bid, kz, nz, kchunk;
-    if (bid0 < sk_n0) {
-        bid = y3_div(bid0, dv_s0);
-        kz = bid0 - bid * sk_s0;
-        nz = sk_s0;
-        kchunk = sk_c0;
-    } else {
-        const int t = bid0 - sk_n0;
-        const int q = y3_div(t, dv_s1);
-        bid = sk_f + q;
-        kz = t - q * sk_s1;
-        nz = sk_s1;
-        kchunk = sk_c1;
-    }
-    // tile id -> (row tile, column tile).  Ids are contiguous per XCD (y3_xcd_remap), so the fastest-varying coordinate decides
-    // which operand an XCD's private 4 MB L2 keeps: row-major ids walk all column tiles of a few row tiles (the activation
-    // rows stay, the whole kernel matrix streams through once per row tile), column-major ids walk all row tiles of a few
-    // column tiles (a slice of the kernel matrix stays, the activations stream).  The host picks column-major when the kernel
-    // matrix is too large to stay resident (> 2 MB): 13x13 512->1024 3x3 fetched its 18.9 MB of weights ~24 times per launch.
-    // nb_fast is the count of the fastest-varying coordinate (nbm when column-major, else nbn).
-    const int tq = y3_div(bid, dv_nb), tr = bid - tq * nb_fast;
-    const int bm = col_major ? tr : tq;
-    const int bn = col_major ? tq : tr;
-    const int m0 = bm * BM, n0 = bn * BN;
-    const int kbeg = kz * kchunk * BK;
-    const int kend = min(aK, kbeg + kchunk * BK);
+    const FastWork fw = conv_fast_decode<BM, BN, WM, WN, BK>(p, braw, grid);
+    const int tid = fw.tid, lane = fw.lane, l31 = fw.l31, lh = fw.lh, wm = fw.wm, wn = fw.wn;
+    const int m0 = fw.m0, n0 = fw.n0, kbeg = fw.kbeg, kend = fw.kend;
+    const int ohw = fw.ohw, OW = fw.OW, aM = fw.aM, aH = fw.aH, aW = fw.aW, src_ld = fw.src_ld, csh = fw.csh, csw = fw.csw, ntaps = fw.ntaps, Nout = fw.Nout;
+    const Y3Div dv_ohw = fw.dv_ohw, dv_ow = fw.dv_ow;
+    (void)lane;
 
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.wt_bytes, 0x00020000);
@@ -656,269 +527,7 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
     }
 
     Y3_TSTAMP(2);
-    if (nz > 1) {
-        // park the raw accumulators: slab[item][r4][thread] as 16-byte stores, one KiB per wave instruction.  The hand-off to the
-        // slice that finishes last follows MI355X_MICROARCH.md (workgroup dispatch, measured hand-offs, row 1): every byte is
-        // stored sc1 (written through, no L2 write-back fence needed) and loaded sc1, every storing wave drains vmcnt before the
-        // workgroup barrier, ONE lane then adds to the tile's ticket with an agent-scope atomic and the workgroup whose add
-        // came last (told by the value returned) loads after a second barrier.
-        constexpr int R4 = MB * NB * 4;
-        const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, 0x7ffffff0, 0x00020000);
-        const unsigned item_bytes = (unsigned)(R4 * THREADS * 16);
-        {
-            const unsigned base = (unsigned)(bid0 - p.sk_slab0) * item_bytes + (unsigned)tid * 16u;
-#pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        f32x4 v = {acc[i][j][4 * r], acc[i][j][4 * r + 1], acc[i][j][4 * r + 2], acc[i][j][4 * r + 3]};
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, base, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
-                    }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int* flag = reinterpret_cast<int*>(&red[0][0][0]);
-        if (tid == 0) {
-            const int old = __hip_atomic_fetch_add(p.tickets + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = old == nz - 1;
-            if (last) __hip_atomic_store(p.tickets + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = last;
-        }
-        __syncthreads();
-        if (*flag == 0) return;
-        __syncthreads();  // `red` is reused by the statistics below
-        const unsigned first = (unsigned)(bid0 - kz - p.sk_slab0) * item_bytes + (unsigned)tid * 16u;   // slice 0 of this tile
-#pragma unroll 1
-        for (int z = 0; z < nz; ++z) {
-            const unsigned base = first + (unsigned)z * item_bytes;
-#pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, base, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[i][j][4 * r + e] = z == 0 ? v[e] : acc[i][j][4 * r + e] + v[e];
-                    }
-        }
-    }
-
-    // ---- epilogue (same contract as conv_igemm_kernel)
-    const bool do_lrelu = p.flags & Y3_EPI_LRELU;
-    const bool do_accum = p.flags & Y3_EPI_ACCUM;
-    float ssum[NB], ssq[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) ssum[j] = ssq[j] = 0.f;
-    float bsum[BNS ? 6 : 1][NB];
-#pragma unroll
-    for (int q = 0; q < (BNS ? 6 : 1); ++q)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) bsum[q][j] = 0.f;
-    if constexpr (DENSE) {
-        // dense destination (pixel index == m): buffer stores with the row part of the offset in the scalar operand and
-        // tile-edge lanes pointed out of range -- no per-element 64-bit address math, no divergent branches.  All 676
-        // workgroups of a layer reach their epilogue together, so its instruction count is exposed, not hidden.
-        const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid ? p.resid : p.dst), 0,
-                                                                               p.resid ? p.resid_bytes : 0u, 0x00020000);
-        const int mrow = m0 + wm * TM + 4 * lh;
-        const unsigned ld4 = (unsigned)p.dst_ld * 4u, rld4 = (unsigned)p.resid_ld * 4u;
-        const bool full = m0 + BM <= p.M;  // wave-uniform: only the last row tile needs per-row masking
-        const bool has_scale = p.scale != nullptr, has_resid = p.resid != nullptr;
-        // BNS: this launch completes the output gradient dy of a BatchNorm layer, so the six raw moments of (dy, a) that its
-        // backward needs (pointwise.hip, bn_bwd_stats_kernel) are summed here, while dy is in registers -- the separate pass
-        // over dy and a is gone.  `a` has the geometry of dst; lanes outside the tile read zeros (no contribution).
-        const __amdgpu_buffer_rsrc_t rs_bna = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNS ? p.bn_a : p.dst), 0, BNS ? p.bn_a_bytes : 0u, 0x00020000);
-        const unsigned ald4 = (unsigned)p.bn_a_ld * 4u;
-        const bool one_extra = has_resid != do_accum;
-        const __amdgpu_buffer_rsrc_t rs_ext = has_resid ? rs_res : rs_dst;
-        const unsigned xld4 = has_resid ? rld4 : ld4;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int n = n0 + wn * TN + j * 32 + l31;
-            const bool nok = n < p.Nout;
-            const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
-            const float sc = (has_scale && nok) ? p.scale[n] : 1.f;
-            const float sf = (has_scale && nok) ? p.shift[n] : 0.f;
-            const unsigned vbase = nok ? (unsigned)mrow * ld4 + (unsigned)n * 4u : Y3_OOB;
-            const unsigned rbase = nok ? (unsigned)mrow * rld4 + (unsigned)n * 4u : Y3_OOB;
-            const unsigned abase = nok ? (unsigned)mrow * ald4 + (unsigned)n * 4u : Y3_OOB;
-            const unsigned xbase = has_resid ? rbase : vbase;
-            // Exactly one extra operand per element (the residual of an inference layer, or the gradient a data gradient adds
-            // to): its loads are issued eight at a time from the one descriptor in use, then consumed.  As single loads inside the
-            // arithmetic they were sixteen dependent memory round trips per 32x32 block.  (Eight, not sixteen, in flight: the 64x64
-            // kernel must stay within 64 VGPRs -- 8 workgroups per CU -- see `red`.)
-            if (!BNS && one_extra) {
-#pragma unroll
-                for (int i = 0; i < MB; ++i) {
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        float ext[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int r = g * 8 + q;
-                            const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
-                            const bool ok = full ? nok : (nok && mrow + dr < p.M);
-                            ext[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_ext, ok ? xbase : Y3_OOB, (unsigned)dr * xld4, 0));
-                        }
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int r = g * 8 + q;
-                            const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
-                            const bool ok = full ? nok : (nok && mrow + dr < p.M);
-                            const unsigned vo = ok ? vbase : Y3_OOB;
-                            float v = acc[i][j][r] + bias;
-                            if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
-                            const float vs = ok ? v : 0.f;
-                            ssum[j] += vs;
-                            ssq[j] += vs * vs;
-                            if (has_scale) v = v * sc + sf;
-                            v += ext[q];
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_dst, vo, (unsigned)dr * ld4, 0);
-                        }
-                    }
-                }
-                continue;
-            }
-#pragma unroll
-            for (int i = 0; i < MB; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
-                    const bool ok = full ? nok : (nok && mrow + dr < p.M);
-                    const unsigned vo = ok ? vbase : Y3_OOB;
-                    float v = acc[i][j][r] + bias;
-                    if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
-                    const float vs = ok ? v : 0.f;
-                    if constexpr (!BNS) {
-                        ssum[j] += vs;
-                        ssq[j] += vs * vs;
-                    }
-                    if (has_scale) v = v * sc + sf;
-                    if (has_resid) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, ok ? rbase : Y3_OOB, (unsigned)dr * rld4, 0));
-                    if (do_accum) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_dst, vo, (unsigned)dr * ld4, 0));
-                    if constexpr (BNS) {
-                        const float av = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_bna, ok ? abase : Y3_OOB, (unsigned)dr * ald4, 0));
-                        const float dv = ok ? v : 0.f;
-                        const bool pos = av > 0.f;
-                        bsum[0][j] += dv;
-                        bsum[1][j] += dv * av;
-                        bsum[2][j] += pos ? dv : 0.f;
-                        bsum[3][j] += pos ? av : 0.f;
-                        bsum[4][j] += pos ? 1.f : 0.f;
-                        bsum[5][j] += av;
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_dst, vo, (unsigned)dr * ld4, 0);
-                }
-            }
-        }
-    } else {
-        // strided destination (the four parity launches of a stride-2 data gradient): decompose each accumulator row
-        // once (not once per column block), then the same buffer-store epilogue as above
-        const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid ? p.resid : p.dst), 0,
-                                                                               p.resid ? p.resid_bytes : 0u, 0x00020000);
-        const bool has_scale = p.scale != nullptr, has_resid = p.resid != nullptr;
-        const __amdgpu_buffer_rsrc_t rs_bna = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNS ? p.bn_a : p.dst), 0, BNS ? p.bn_a_bytes : 0u, 0x00020000);
-        unsigned rowpix[MB][16];
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int mm = m < p.M ? m : 0;
-                const int nimg = y3_div(mm, dv_ohw);
-                const int rr = mm - nimg * ohw;
-                const int oh = y3_div(rr, dv_ow);
-                const int ow = rr - oh * OW;
-                const unsigned pix = (unsigned)((nimg * p.DH + oh * p.dsh + p.doh) * p.DW + ow * p.dsw + p.dow);
-                rowpix[i][r] = m < p.M ? pix : 0xffffffffu;
-            }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int n = n0 + wn * TN + j * 32 + l31;
-            const bool nok = n < p.Nout;
-            const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
-            const float sc = (has_scale && nok) ? p.scale[n] : 1.f;
-            const float sf = (has_scale && nok) ? p.shift[n] : 0.f;
-#pragma unroll
-            for (int i = 0; i < MB; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const bool ok = nok && rowpix[i][r] != 0xffffffffu;
-                    const unsigned vo = ok ? (rowpix[i][r] * (unsigned)p.dst_ld + (unsigned)n) * 4u : Y3_OOB;
-                    float v = acc[i][j][r] + bias;
-                    if (do_lrelu) v = v > 0.f ? v : p.alpha * v;
-                    const float vs = ok ? v : 0.f;
-                    ssum[j] += vs;
-                    ssq[j] += vs * vs;
-                    if (has_scale) v = v * sc + sf;
-                    if (has_resid)
-                        v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, ok ? (rowpix[i][r] * (unsigned)p.resid_ld + (unsigned)n) * 4u : Y3_OOB, 0, 0));
-                    if (do_accum) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_dst, vo, 0, 0));
-                    if constexpr (BNS) {      // the same six moments as in the dense epilogue; `a` has the geometry of the strided destination
-                        const float av = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_bna, ok ? (rowpix[i][r] * (unsigned)p.bn_a_ld + (unsigned)n) * 4u : Y3_OOB, 0, 0));
-                        const float dv = ok ? v : 0.f;
-                        const bool pos = av > 0.f;
-                        bsum[0][j] += dv;
-                        bsum[1][j] += dv * av;
-                        bsum[2][j] += pos ? dv : 0.f;
-                        bsum[3][j] += pos ? av : 0.f;
-                        bsum[4][j] += pos ? 1.f : 0.f;
-                        bsum[5][j] += av;
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_dst, vo, 0, 0);
-                }
-            }
-        }
-    }
-    if constexpr (BNS) {
-        // fixed order: lane halves, then the WM waves of a column -- deterministic, no atomics (as the forward statistics below)
-        __syncthreads();      // `red` aliases the A stage: every wave must be done with its last fragment reads
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const float s = bsum[q][j] + __shfl_xor(bsum[q][j], 32);
-                if (lh == 0) red[q][wm][wn * TN + j * 32 + l31] = s;
-            }
-        __syncthreads();
-        for (int c = tid; c < 6 * BN; c += THREADS) {
-            const int which = c / BN, col = c % BN;
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) s += red[which][w][col];
-            const int n = n0 + col;
-            if (n < p.Nout) p.bn_part[((long long)(p.bn_row0 + bm) * 6 + which) * p.Nout + n] = s;
-        }
-    } else if (p.stats) {
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const float s = ssum[j] + __shfl_xor(ssum[j], 32);
-            const float q = ssq[j] + __shfl_xor(ssq[j], 32);
-            if (lh == 0) {
-                red[0][wm][wn * TN + j * 32 + l31] = s;
-                red[1][wm][wn * TN + j * 32 + l31] = q;
-            }
-        }
-        __syncthreads();
-        for (int c = tid; c < 2 * BN; c += THREADS) {
-            const int which = c / BN, col = c % BN;
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) s += red[which][w][col];
-            const int n = n0 + col;
-            if (n < p.Nout) p.stats[((long long)bm * 2 + which) * p.Nout + n] = s;
-        }
-    }
-#ifdef Y3_TIMING
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (y3_timing_buf && threadIdx.x == 0) y3_timing_buf[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
-#endif
-    Y3_TSTAMP(3);
+    conv_fast_finish<BM, BN, WM, WN, DENSE, BNS>(p, fw, acc, red);
 }
 
 // registers: at least 3 waves per SIMD; the BNS 64x64 variant must also stay at 64 VGPRs (8 waves per SIMD like its plain twin, see `red`)
@@ -1417,8 +1026,51 @@ struct ConvPlan {
 };
 // The K loop of conv_fast_body runs its steps in pairs (an odd count is padded with a dead step): slices get an even step count.
 static inline int even_steps(int chunk) { return chunk + (chunk & 1); }
+// The x3 kernels (conv_x3.hip): 128 x 128 tiles (128 x 64 for <= 64 output columns), two to three workgroups per CU.  Every
+// launch of the layers they are used for is cut along K into slices of >= 12 K steps so that ~700 workgroups share the work
+// evenly -- 2.7 per CU, dealt out as slots free up -- e.g. 338 tiles x 2, 172 x 4, 88 x 8 slices of 36 steps for the 3x3 layers
+// of the 52 / 26 / 13 grids at batch 8.
+static bool x3_shape_ok(int C, int Nout, int K, int ntaps) {
+    return C % 16 == 0 && K % 16 == 0 && (ntaps == 1 || y3_is_pow2(C)) && Nout >= 32 && K / 16 >= 2;
+}
+static ConvPlan plan_conv_x3(int M, int Nout, int K) {
+    ConvPlan pl;
+    pl.t = {128, Nout <= 64 ? 64 : 128, 16};
+    {
+        static const int force_bn = env_int("Y3_X3_BN", 0);      // development: 64 = 128 x 64 tiles everywhere
+        if (force_bn == 64 || force_bn == 128) pl.t.bn = Nout <= 64 ? 64 : force_bn;
+    }
+    const int tiles = y3_cdiv(M, pl.t.bm) * y3_cdiv(Nout, pl.t.bn);
+    const int nk = K / 16;
+    pl.tiles = pl.f = tiles;
+    pl.s0 = pl.s1 = 1;
+    pl.chunk0 = pl.chunk1 = even_steps(nk);
+    static const int want = env_int("Y3_X3_WGS", 700);
+    static const int min_steps = env_int("Y3_X3_MINSTEPS", 12);
+    if (tiles <= Y3_MAX_TICKETS && tiles * 4 <= want * 3) {
+        int ks = (want + tiles / 2) / tiles;
+        if (ks > nk / min_steps) ks = nk / min_steps;
+        if (ks > 16) ks = 16;
+        if (ks > 1) {
+            pl.chunk0 = even_steps(y3_cdiv(nk, ks));
+            pl.s0 = y3_cdiv(nk, pl.chunk0);
+        }
+    }
+    pl.stats_tiles = y3_cdiv(M, pl.t.bm);
+    const long long split_items = pl.s0 > 1 ? (long long)tiles * pl.s0 : 0;
+    const long long slab_bytes = split_items * pl.t.bm * pl.t.bn * 4;
+    if (slab_bytes >= 0x7ff00000LL) {
+        pl.s0 = 1;
+        pl.chunk0 = even_steps(nk);
+        pl.ws_bytes = 0;
+    } else {
+        pl.ws_bytes = split_items > 0 ? (size_t)Y3_WS_HEADER + (size_t)slab_bytes : 0;
+    }
+    return pl;
+}
 // fast_ok: the launch qualifies for conv_igemm_fast_kernel (the only kernel with split-K)
-static ConvPlan plan_conv(int M, int Nout, int K, bool fast_ok) {
+static ConvPlan plan_conv(int M, int Nout, int K, bool fast_ok, bool x3 = false) {
+    if (x3) return plan_conv_x3(M, Nout, K);
     ConvPlan pl;
     pl.t = pick_tile(M, Nout);
     const int tiles = y3_cdiv(M, pl.t.bm) * y3_cdiv(Nout, pl.t.bn);
@@ -1503,14 +1155,21 @@ static bool fast_shape_ok(int C, int Nout, int K, int ntaps) {
     return !getenv("Y3_NO_FAST") && C % 16 == 0 && K % 16 == 0 && (ntaps == 1 || y3_is_pow2(C));
 }
 
-extern "C" int y3_conv2d_stats_tiles(int m, int cin, int ksize, int cout) {
-    const int taps = ksize * ksize;
-    return plan_conv(m, cout, taps * cin, fast_shape_ok(cin, cout, taps * cin, taps)).stats_tiles;
+extern "C" int y3_conv2d_x3_ok(int m, int c, int ntaps, int nout) {
+    return (m > 0 && (ntaps == 1 || ntaps == 9 || ntaps == 2 || ntaps == 4) && x3_shape_ok(c, nout, ntaps * c, ntaps)) ? 1 : 0;
 }
-extern "C" size_t y3_conv2d_fwd_workspace(int m, int cin, int ksize, int cout) {
+extern "C" int y3_conv2d_stats_tiles_x(int m, int cin, int ksize, int cout, unsigned flags) {
     const int taps = ksize * ksize;
-    return plan_conv(m, cout, taps * cin, fast_shape_ok(cin, cout, taps * cin, taps)).ws_bytes;
+    const bool x3 = (flags & Y3_CONV_X3) && x3_shape_ok(cin, cout, taps * cin, taps);
+    return plan_conv(m, cout, taps * cin, fast_shape_ok(cin, cout, taps * cin, taps), x3).stats_tiles;
 }
+extern "C" size_t y3_conv2d_fwd_workspace_x(int m, int cin, int ksize, int cout, unsigned flags) {
+    const int taps = ksize * ksize;
+    const bool x3 = (flags & Y3_CONV_X3) && x3_shape_ok(cin, cout, taps * cin, taps);
+    return plan_conv(m, cout, taps * cin, fast_shape_ok(cin, cout, taps * cin, taps), x3).ws_bytes;
+}
+extern "C" int y3_conv2d_stats_tiles(int m, int cin, int ksize, int cout) { return y3_conv2d_stats_tiles_x(m, cin, ksize, cout, 0u); }
+extern "C" size_t y3_conv2d_fwd_workspace(int m, int cin, int ksize, int cout) { return y3_conv2d_fwd_workspace_x(m, cin, ksize, cout, 0u); }
 
 // Diagnostics (include/yolo3hip.h): the plan behind y3_conv2d_fwd / stride-1 y3_conv2d_dgrad for an M x cout x (ksize^2 cin) GEMM
 extern "C" size_t y3_conv2d_plan(int m, int cin, int ksize, int cout, int* out13) {
@@ -1565,6 +1224,7 @@ static bool make_fast(const ConvArgs& a, int ntaps, int bk, FastArgs* f) {
     p.src = a.src ? a.src + min_off : nullptr;      // (null in the dry runs of the *_tiles queries)
     p.src_bytes = (unsigned)(total * 4);
     p.wt = a.wt;
+    p.Cper = a.C;
     p.wt_bytes = (unsigned)(wtotal * 4);
     for (int t = 0; t < ntaps; ++t) {
         p.tap_dh[t] = dh[t];
@@ -1642,12 +1302,17 @@ static bool make_fast(const ConvArgs& a, int ntaps, int bk, FastArgs* f) {
 static int launch_igemm(const ConvArgs& a, void* workspace, size_t workspace_bytes, hipStream_t st) {
     ConvArgs p = a;
     const int ntaps = p.K / p.C;
-    const bool fast_ok = fast_shape_ok(p.C, p.Nout, p.K, ntaps);
-    ConvPlan pl = plan_conv(p.M, p.Nout, p.K, fast_ok);
+    const bool x3 = p.x3 != 0;
+    if (x3 && !x3_shape_ok(p.C, p.Nout, p.K, ntaps)) {
+        y3_set_error("conv: Y3_CONV_X3 does not take this shape (C %d, Nout %d, K %d): ask y3_conv2d_x3_ok() first", p.C, p.Nout, p.K);
+        return Y3_EINVAL;
+    }
+    const bool fast_ok = x3 || fast_shape_ok(p.C, p.Nout, p.K, ntaps);
+    ConvPlan pl = plan_conv(p.M, p.Nout, p.K, fast_ok, x3);
     if (pl.ws_bytes > 0 && (workspace == nullptr || workspace_bytes < pl.ws_bytes)) {  // no room for slabs: whole tiles
         pl.f = pl.tiles;
         pl.s0 = pl.s1 = 1;
-        pl.chunk0 = pl.chunk1 = p.K / pl.t.bk;
+        pl.chunk0 = pl.chunk1 = even_steps(p.K / pl.t.bk);
         pl.ws_bytes = 0;
     }
     const TileCfg t = pl.t;
@@ -1685,6 +1350,14 @@ static int launch_igemm(const ConvArgs& a, void* workspace, size_t workspace_byt
             y3_set_error("conv: BatchNorm-backward statistics need the dense fast kernel with K steps of 16");
             return Y3_EINVAL;
         }
+        if (x3) {
+            if (!y3_x3_launch(f, t.bm, t.bn, dense, grid, st)) {
+                y3_set_error("conv: no x3 kernel for tile %dx%d", t.bm, t.bn);
+                return Y3_EINVAL;
+            }
+            Y3_CHECK_LAUNCH("conv_x3");
+            return Y3_OK;
+        }
         switch (key) {
             case 128 * 10000 + 128 * 10 + 0: launch_fast<128, 128, 2, 2, 16>(f, dense, grid, st); break;
             case 128 * 10000 + 64 * 10 + 0: launch_fast<128, 64, 4, 1, 16>(f, dense, grid, st); break;
@@ -1696,8 +1369,8 @@ static int launch_igemm(const ConvArgs& a, void* workspace, size_t workspace_byt
         Y3_CHECK_LAUNCH("conv_igemm_fast");
         return Y3_OK;
     }
-    if (p.bn_a) {
-        y3_set_error("conv: BatchNorm-backward statistics are not available on the generic kernel (shape %d x %d x %d)", p.M, p.Nout, p.K);
+    if (p.bn_a || x3) {
+        y3_set_error("conv: %s not available on the generic kernel (shape %d x %d x %d)", x3 ? "Y3_CONV_X3 is" : "BatchNorm-backward statistics are", p.M, p.Nout, p.K);
         return Y3_EINVAL;
     }
     const int grid = tiles;
@@ -1781,7 +1454,8 @@ extern "C" int y3_conv2d_fwd(const y3_tensor* src, const float* wt, const float*
     p.Nout = dst->c;
     p.K = taps * src->c;
     p.M = src->n * OH * OW;
-    p.flags = flags;
+    p.flags = flags & ~Y3_CONV_X3;
+    p.x3 = (flags & Y3_CONV_X3) ? 1 : 0;
     p.alpha = alpha;
     p.src_n = src->n;
     p.wt_rows = taps * src->c;
@@ -1789,10 +1463,14 @@ extern "C" int y3_conv2d_fwd(const y3_tensor* src, const float* wt, const float*
 }
 
 extern "C" size_t y3_conv2d_dgrad_workspace(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc) {
+    return y3_conv2d_dgrad_workspace_x(ddst, ksize, stride, dsrc, 0u);
+}
+extern "C" size_t y3_conv2d_dgrad_workspace_x(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc, unsigned flags) {
     const int taps = ksize * ksize;
     if (stride == 1) {
         const int K = taps * ddst->c;
-        return plan_conv(dsrc->n * dsrc->h * dsrc->w, dsrc->c, K, fast_shape_ok(ddst->c, dsrc->c, K, taps)).ws_bytes;
+        const bool x3 = (flags & Y3_CONV_X3) && x3_shape_ok(ddst->c, dsrc->c, K, taps);
+        return plan_conv(dsrc->n * dsrc->h * dsrc->w, dsrc->c, K, fast_shape_ok(ddst->c, dsrc->c, K, taps), x3).ws_bytes;
     }
     size_t best = 0;
     for (int nt = 1; nt <= 4; nt *= 2) {  // parity classes carry 1, 2, 2 and 4 taps of a 3x3 kernel
@@ -1868,6 +1546,9 @@ static bool launch_dgrad_multi(const ConvArgs* cls, int ncls, hipStream_t st, in
 static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc, unsigned flags,
                              const y3_tensor* bn_a, float* bn_partials, void* workspace, size_t workspace_bytes, y3_stream_t stream,
                              int* dry_rows = nullptr);
+static bool dgrad_x3(unsigned flags, const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc) {
+    return (flags & Y3_CONV_X3) && stride == 1 && ddst && dsrc && x3_shape_ok(ddst->c, dsrc->c, ksize * ksize * ddst->c, ksize * ksize);
+}
 
 extern "C" int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc, unsigned flags,
                                void* workspace, size_t workspace_bytes, y3_stream_t stream) {
@@ -1877,6 +1558,9 @@ extern "C" int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksi
 // Row tiles of the partial statistics y3_conv2d_dgrad_bn writes for this shape, 0 if the shape does not qualify (stride 2,
 // channel counts off the fast path): the caller then runs y3_bn_bwd_stats on the finished gradient instead.
 extern "C" int y3_conv2d_dgrad_bn_tiles(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc) {
+    return y3_conv2d_dgrad_bn_tiles_x(ddst, ksize, stride, dsrc, 0u);
+}
+extern "C" int y3_conv2d_dgrad_bn_tiles_x(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc, unsigned flags) {
     if (!ddst || !dsrc || (ksize != 1 && ksize != 3)) return 0;
     if (stride == 2) {      // the merged launch of the four parity classes: rows of all classes, or 0 if it would not be taken
         if (ksize != 3 || ddst->h != (dsrc->h + 1) / 2 || ddst->w != (dsrc->w + 1) / 2 || ddst->n != dsrc->n) return 0;
@@ -1887,12 +1571,13 @@ extern "C" int y3_conv2d_dgrad_bn_tiles(const y3_tensor* ddst, int ksize, int st
     if (stride != 1) return 0;
     if (ddst->h != dsrc->h || ddst->w != dsrc->w || ddst->n != dsrc->n) return 0;
     const int taps = ksize * ksize, K = taps * ddst->c, M = dsrc->n * dsrc->h * dsrc->w;
-    if (!fast_shape_ok(ddst->c, dsrc->c, K, taps)) return 0;
-    const ConvPlan pl = plan_conv(M, dsrc->c, K, true);
+    const bool x3 = dgrad_x3(flags, ddst, ksize, stride, dsrc);
+    if (!x3 && !fast_shape_ok(ddst->c, dsrc->c, K, taps)) return 0;
+    const ConvPlan pl = plan_conv(M, dsrc->c, K, true, x3);
     if (pl.t.bk != 16) return 0;
     // the launch itself must be accepted too (2 GiB buffer limits, tap grid): dry run of the argument builder
     int ok = 0;
-    if (conv2d_dgrad_impl(ddst, nullptr, ksize, 1, dsrc, 0, nullptr, nullptr, nullptr, 0, nullptr, &ok) != Y3_OK || !ok) return 0;
+    if (conv2d_dgrad_impl(ddst, nullptr, ksize, 1, dsrc, x3 ? Y3_CONV_X3 : 0u, nullptr, nullptr, nullptr, 0, nullptr, &ok) != Y3_OK || !ok) return 0;
     return y3_cdiv(M, pl.t.bm);
 }
 
@@ -1902,7 +1587,7 @@ extern "C" int y3_conv2d_dgrad_bn(const y3_tensor* ddst, const float* wt_t, int 
     Y3_CHECK_ARG(bn_partials, "conv2d_dgrad_bn: null partials");
     Y3_CHECK_ARG(dsrc && bn_a->n == dsrc->n && bn_a->h == dsrc->h && bn_a->w == dsrc->w && bn_a->c == dsrc->c, "conv2d_dgrad_bn: bn_a must have dsrc's geometry");
     Y3_CHECK_ARG((long long)bn_a->n * bn_a->h * bn_a->w * bn_a->ld * 4 < 0x7fffffffLL, "conv2d_dgrad_bn: bn_a of 2 GiB or more");
-    Y3_CHECK_ARG(y3_conv2d_dgrad_bn_tiles(ddst, ksize, stride, dsrc) > 0, "conv2d_dgrad_bn: shape does not qualify (y3_conv2d_dgrad_bn_tiles() == 0)");
+    Y3_CHECK_ARG(y3_conv2d_dgrad_bn_tiles_x(ddst, ksize, stride, dsrc, flags) > 0, "conv2d_dgrad_bn: shape does not qualify (y3_conv2d_dgrad_bn_tiles() == 0)");
     return conv2d_dgrad_impl(ddst, wt_t, ksize, stride, dsrc, flags, bn_a, bn_partials, workspace, workspace_bytes, stream);
 }
 
@@ -1918,7 +1603,8 @@ static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize
     Y3_CHECK_ARG(stride == 1 || stride == 2, "conv2d_dgrad: stride %d unsupported", stride);
     const int OH = (dsrc->h + stride - 1) / stride, OW = (dsrc->w + stride - 1) / stride;
     Y3_CHECK_ARG(ddst->n == dsrc->n && ddst->h == OH && ddst->w == OW, "conv2d_dgrad: geometry mismatch");
-    Y3_CHECK_ARG((flags & ~Y3_EPI_ACCUM) == 0, "conv2d_dgrad: only Y3_EPI_ACCUM allowed");
+    Y3_CHECK_ARG((flags & ~(Y3_EPI_ACCUM | Y3_CONV_X3)) == 0, "conv2d_dgrad: only Y3_EPI_ACCUM and Y3_CONV_X3 allowed");
+    Y3_CHECK_ARG(!(flags & Y3_CONV_X3) || dgrad_x3(flags, ddst, ksize, stride, dsrc), "conv2d_dgrad: Y3_CONV_X3 takes stride-1 shapes that pass y3_conv2d_x3_ok()");
     const int pbh = y3_same_pad_before(dsrc->h, ksize, stride), pbw = y3_same_pad_before(dsrc->w, ksize, stride);
     // the contraction runs over (tap, cout): channels of ddst
     ConvArgs base = {};
@@ -1931,7 +1617,8 @@ static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize
     base.src_ld = ddst->ld;
     base.dst_ld = dsrc->ld;
     base.Nout = dsrc->c;
-    base.flags = flags;
+    base.flags = flags & ~Y3_CONV_X3;
+    base.x3 = (flags & Y3_CONV_X3) ? 1 : 0;
     base.DH = dsrc->h;
     base.DW = dsrc->w;
     base.sh = base.sw = 1;
@@ -1956,7 +1643,7 @@ static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize
         p.M = dsrc->n * p.OH * p.OW;
         if (dry_rows) {      // would launch_igemm take the fast kernel for this shape?  (pointers are not dereferenced)
             FastArgs f;
-            *dry_rows = (fast_shape_ok(p.C, p.Nout, p.K, taps) && make_fast(p, taps, 16, &f)) ? 1 : 0;
+            *dry_rows = ((p.x3 || fast_shape_ok(p.C, p.Nout, p.K, taps)) && make_fast(p, taps, 16, &f)) ? 1 : 0;
             return Y3_OK;
         }
         if (bn_a) {

@@ -1,0 +1,349 @@
+// fp32 convolution arithmetic on the bf16 matrix pipe of gfx950 ("x3"): the forward pass and the data gradient of the
+// MFMA fast path (conv_fast.h) with every operand element cut into three bf16 pieces.
+//
+//   x = x0 + x1 + x2 exactly:  x0 = bf16(x), x1 = bf16(x - x0), x2 = x - x0 - x1      (round to nearest even; 8 + 8 + 8
+//   significant bits, the residuals are exact in fp32 and the last one is exactly a bf16)
+//   a * b = sum over the piece pairs; the six pairs with piece indices i + j <= 2 are multiplied, the other three are
+//   below 2^-26 of the product (fp32 rounding of the running sum is 2^-24): the result is fp32-class, not bf16-class.
+//
+// One K step of 16 is ONE v_mfma_f32_32x32x16_bf16 per piece pair and 32x32 block: 6 x 32 cycles where
+// v_mfma_f32_32x32x2_f32 needs 8 x 64 -- 2.67x fewer matrix-pipe cycles for the same fp32 product, fp32 accumulation.
+// The accumulator layout is that of the fp32 instruction, so the split-K hand-off and the epilogue are conv_fast_finish().
+//
+// Why a kernel of its own (round 3 measured the same arithmetic as a variant of conv_fast_body at +1 %): with 32x32 wave
+// tiles a wave has 6 MFMAs (192 cycles) per barrier, too little to cover the barrier, the split (5 vector instructions per
+// element) and the LDS round trip.  Here a wave owns 64 x 64 (24 MFMAs = 768 cycles per K step), its fragments are read
+// one PIECE ahead (not a whole set ahead: 56 instead of 96 fragment registers), and every MFMA is followed by a slot that
+// carries at most a handful of vector / LDS instructions:
+//   slots of groups 0 .. GB-1  reads of this step's remaining pieces, then split + LDS stores of the NEXT step's tile
+//                              (global data loaded two steps earlier), four sub-steps of <= 6 vector instructions per 16 bytes
+//   LDS-only barrier           global loads stay in flight across it
+//   slots of the other groups  reads of the next step's first pieces, global loads for the step THREE ahead
+// Weights are read from the copy of the kernel whose K axis is contiguous per output column (forward: the transposed copy
+// [tap][Cout][Cin]; data gradient: the Keras copy [tap][Cin][Cout]), so both operands share one loader and one LDS image:
+// [piece][k half][row][8 k] bf16, the 32 lanes of a fragment read (one k half, consecutive rows) cover 512 contiguous bytes.
+#include "conv_fast.h"
+
+typedef __bf16 y3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 y3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float y3_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned x3_pk(float a, float b) {      // v_cvt_pk_bf16_f32: two roundings to nearest even, a in the low half
+    const y3_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, y3_bf16x2));
+}
+__device__ __forceinline__ float x3_lo(unsigned pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float x3_hi(unsigned pk) { return __uint_as_float(pk & 0xffff0000u); }
+
+#ifndef Y3_X3_GB
+#define Y3_X3_GB 4      // the barrier sits after MFMA group GB - 1 (of 6)
+#endif
+
+template <int BM, int BN, int WM, int WN, bool DENSE, bool BNS>
+__device__ __forceinline__ void conv_x3_body(const FastArgs& p, const int braw, const int grid) {
+    constexpr int BK = 16, KV = 4;
+    constexpr int THREADS = 64 * WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
+    constexpr int A_LOADS = BM * KV / THREADS, B_LOADS = BN * KV / THREADS;
+    static_assert((BM * KV) % THREADS == 0 && (BN * KV) % THREADS == 0 && TM % 32 == 0 && TN % 32 == 0, "tile shape");
+    // k-half planes are 64 bytes longer than their rows: LDS stores are banked by (address / 4) mod 32, and without the pad the
+    // two halves a 16-lane store group writes fall on the same banks
+    constexpr int AH = BM * 8 + 32, BH = BN * 8 + 32;       // u16 per k half
+    constexpr int A3 = 6 * AH, B3 = 6 * BH, BUF = A3 + B3;  // u16 per piece set / per buffer
+    constexpr int RED = (BNS ? 6 : 2) * WM * BN;            // floats: column sums of the epilogue
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * BUF + 2 * RED];
+    float (*red)[WM][BN] = reinterpret_cast<float (*)[WM][BN]>(&lds[2 * BUF]);
+
+    Y3_TSTAMP(0);
+    Y3_ABL_INIT();
+#ifdef Y3_TIMING
+    if (y3_timing_buf && threadIdx.x == 0) {
+        y3_timing_buf[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+        y3_timing_buf[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+        y3_timing_buf[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    const FastWork fw = conv_fast_decode<BM, BN, WM, WN, BK>(p, braw, grid);
+    const int tid = fw.tid, l31 = fw.l31, lh = fw.lh, wm = fw.wm, wn = fw.wn;
+    const int m0 = fw.m0, n0 = fw.n0, kbeg = fw.kbeg, kend = fw.kend;
+    const int ohw = fw.ohw, OW = fw.OW, aM = fw.aM, aH = fw.aH, aW = fw.aW, src_ld = fw.src_ld, csh = fw.csh, csw = fw.csw, ntaps = fw.ntaps, Nout = fw.Nout;
+    const Y3Div dv_ohw = fw.dv_ohw, dv_ow = fw.dv_ow;
+
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.wt_bytes, 0x00020000);
+
+    // loop-invariant per-lane offsets: thread -> (row idx / 4, k quad idx % 4) of both operand tiles
+    unsigned a_voff[A_LOADS], a_mask[A_LOADS], b_voff[B_LOADS];
+    const int a_kv = tid % KV;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int row = (tid + i * THREADS) / KV;
+        const int m = m0 + row;
+        const bool ok = m < aM;
+        const int mm = ok ? m : 0;
+        const int n = y3_div(mm, dv_ohw);
+        const int r = mm - n * ohw;
+        const int oh = y3_div(r, dv_ow);
+        const int ow = r - oh * OW;
+        const int ih0 = oh * csh, iw0 = ow * csw;
+        a_voff[i] = (unsigned)(((n * aH + ih0) * aW + iw0) * src_ld + a_kv * 4) * 4u;
+        unsigned msk = 0;
+        for (int t = 0; t < ntaps; ++t) {
+            const int ih = ih0 + p.tap_dh[t], iw = iw0 + p.tap_dw[t];
+            if (ok && (unsigned)ih < (unsigned)aH && (unsigned)iw < (unsigned)aW) msk |= 1u << t;
+        }
+        a_mask[i] = msk;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int n = n0 + (tid + i * THREADS) / KV;
+        b_voff[i] = n < Nout ? (unsigned)(n * p.Cper + a_kv * 4) * 4u : Y3_OOB;
+    }
+    // LDS addresses (u16 units): this thread's 8-byte store slot of a piece plane, and its 16-byte fragment slot
+    const int a_st = (a_kv >> 1) * AH + (tid / KV) * 8 + (a_kv & 1) * 4;
+    const int b_st = (a_kv >> 1) * BH + (tid / KV) * 8 + (a_kv & 1) * 4;
+    const int a_fr = lh * AH + (wm * TM + l31) * 8;
+    const int b_fr = lh * BH + (wn * TN + l31) * 8;
+
+    // Global -> register staging: TWO register sets (tile of K step s in set s & 1), loads issued three steps ahead
+    // (conv_fast_body); dead steps at or beyond kend fetch nothing and return zeros.
+    f32x4 ra[2][A_LOADS], rb[2][B_LOADS];
+    struct Soff {
+        int tap, cb, toff, wrow;
+        unsigned dead;
+    };
+    auto soff_prep = [&](int k0) {
+        Soff o;
+        const bool live = k0 < kend;
+        o.dead = live ? 0u : Y3_OOB;
+        k0 = live ? k0 : kbeg;
+        o.tap = k0 >> p.logC;  // wave-uniform: scalar unit
+        o.cb = k0 & p.cmask;
+        const int ty = (o.tap * p.tg_mul) >> 5;                  // tap / tg_nx for tap < 9
+        const int tx = o.tap - ty * p.tg_nx;
+        o.toff = p.tg_off0 + ty * p.tg_offy + tx * p.tg_offx;
+        o.wrow = p.tg_w0 + ty * p.tg_wy + tx * p.tg_wx;         // (weight tap) * C
+        o.tap = live ? o.tap : 31;
+        return o;
+    };
+    auto gload_one = [&](const Soff& o, auto S, auto E) {
+        constexpr int set = decltype(S)::value, e = decltype(E)::value;
+        if constexpr (e < A_LOADS) {
+            const unsigned vo = ((a_mask[e] >> o.tap) & 1u) ? a_voff[e] : Y3_OOB;
+            ra[set][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, vo, (unsigned)(o.toff + o.cb * 4), 0);
+        } else {
+            // the tap's block of the K-contiguous kernel copy starts at (weight tap) * C * Nout floats
+            rb[set][e - A_LOADS] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[e - A_LOADS] | o.dead, (unsigned)(o.wrow * p.Nout + o.cb) * 4u, 0);
+        }
+    };
+    constexpr int NW = A_LOADS + B_LOADS;
+    auto gload = [&](int k0, auto S) {
+        const Soff o = soff_prep(k0);
+        y3_for_each_ic(std::make_integer_sequence<int, NW>{}, [&](auto E) { gload_one(o, S, E); });
+    };
+
+    // Split + store of one 16-byte load (4 consecutive k of one row) in four sub-steps of <= 6 vector instructions; the
+    // residual overwrites the staging register.
+    unsigned pk0 = 0, pk1 = 0;
+    auto st_addr = [&](auto W, int buf, int piece) -> unsigned short* {
+        constexpr int w = decltype(W)::value;
+        if constexpr (w < A_LOADS)
+            return &lds[buf * BUF + piece * 2 * AH + a_st + w * (THREADS / KV) * 8];
+        else
+            return &lds[buf * BUF + A3 + piece * 2 * BH + b_st + (w - A_LOADS) * (THREADS / KV) * 8];
+    };
+    auto split_sub = [&](auto S, auto W, auto SUB, int buf) {
+        constexpr int set = decltype(S)::value, w = decltype(W)::value, sub = decltype(SUB)::value;
+        f32x4& v = [&]() -> f32x4& {
+            if constexpr (w < A_LOADS)
+                return ra[set][w];
+            else
+                return rb[set][w - A_LOADS];
+        }();
+        if constexpr (sub == 0) {
+            pk0 = x3_pk(v[0], v[1]);
+            pk1 = x3_pk(v[2], v[3]);
+            *reinterpret_cast<uint2*>(st_addr(W, buf, 0)) = make_uint2(pk0, pk1);
+            v[0] -= x3_lo(pk0);
+            v[1] -= x3_hi(pk0);
+        } else if constexpr (sub == 1) {
+            v[2] -= x3_lo(pk1);
+            v[3] -= x3_hi(pk1);
+            pk0 = x3_pk(v[0], v[1]);
+            pk1 = x3_pk(v[2], v[3]);
+            *reinterpret_cast<uint2*>(st_addr(W, buf, 1)) = make_uint2(pk0, pk1);
+        } else if constexpr (sub == 2) {
+            v[0] -= x3_lo(pk0);
+            v[1] -= x3_hi(pk0);
+            v[2] -= x3_lo(pk1);
+        } else {
+            v[3] -= x3_hi(pk1);
+            *reinterpret_cast<uint2*>(st_addr(W, buf, 2)) = make_uint2(x3_pk(v[0], v[1]), x3_pk(v[2], v[3]));
+        }
+    };
+    auto split_store_all = [&](auto S, int buf) {     // prologue: the whole tile of register set S
+        y3_for_each_ic(std::make_integer_sequence<int, NW * 4>{}, [&](auto E) {
+            constexpr int e = decltype(E)::value;
+            split_sub(S, std::integral_constant<int, e / 4>{}, std::integral_constant<int, e % 4>{}, buf);
+        });
+    };
+
+    // fragments: [step parity][piece][block]; a step multiplies the piece pairs in the order (0,0) (0,1) (0,2) (1,0) (1,1) (2,0)
+    y3_bf16x8 FA[2][3][MB], FB[2][3][NB];
+    auto read_a = [&](auto F, auto PC, int i, int buf) {
+        FA[decltype(F)::value][decltype(PC)::value][i] =
+            *reinterpret_cast<const y3_bf16x8*>(&lds[buf * BUF + decltype(PC)::value * 2 * AH + a_fr + i * 32 * 8]);
+    };
+    auto read_b = [&](auto F, auto PC, int j, int buf) {
+        FB[decltype(F)::value][decltype(PC)::value][j] =
+            *reinterpret_cast<const y3_bf16x8*>(&lds[buf * BUF + A3 + decltype(PC)::value * 2 * BH + b_fr + j * 32 * 8]);
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    const int nk = (kend - kbeg) / BK;
+    {
+        constexpr int NMG = MB * NB;          // MFMAs per piece pair
+        constexpr int NM = 6 * NMG;           // MFMAs per K step
+        constexpr int SB = Y3_X3_GB * NMG;    // slots in front of the barrier
+        // events in front of the barrier: reads of pieces B2 (needed by group 2), A1 (group 3), A2 (group 5), one per slot from
+        // slot 0; and the NW * 4 split sub-steps, spread evenly over the SB slots
+        constexpr int NR1 = NB + MB + MB;
+        constexpr int NS = NW * 4;
+        // events behind it: reads of the next step's A0, B0, B1, two per slot; then the NW global loads, one per slot
+        constexpr int NR2 = MB + NB + NB;
+        constexpr int SP = NM - SB;
+        constexpr int RS2 = (NR2 + 1) / 2;    // slots taken by the reads
+        static_assert(NR1 <= SB && RS2 < SP, "not enough MFMA slots for the events of a K step");
+        constexpr int LPS = (NW + SP - RS2 - 1) / (SP - RS2);     // global loads per slot
+        constexpr int LS = (NW + LPS - 1) / LPS;                  // slots taken by the loads
+        Soff nxt;
+        int knext = 0;
+        auto slot = [&](auto Mi, auto P) {
+            constexpr int m = decltype(Mi)::value, cur = decltype(P)::value;
+            using F = std::integral_constant<int, cur>;
+            using G = std::integral_constant<int, cur ^ 1>;      // register set stored / reloaded; fragment set of the next step
+            if constexpr (m < SB) {
+                if constexpr (m < NR1) {
+                    if constexpr (m < NB)
+                        read_b(F{}, C2{}, m, cur);
+                    else if constexpr (m < NB + MB)
+                        read_a(F{}, C1{}, m - NB, cur);
+                    else
+                        read_a(F{}, C2{}, m - NB - MB, cur);
+                }
+                constexpr int s0 = m * NS / SB, s1 = (m + 1) * NS / SB;
+                if (!Y3_ABL(2))
+                    y3_for_each_ic(std::make_integer_sequence<int, s1 - s0>{}, [&](auto D) {
+                        constexpr int s = s0 + decltype(D)::value;
+                        split_sub(G{}, std::integral_constant<int, s / 4>{}, std::integral_constant<int, s % 4>{}, cur ^ 1);
+                    });
+            } else {
+                constexpr int q = m - SB;
+                if constexpr (q < RS2) {
+                    y3_for_each_ic(std::make_integer_sequence<int, 2>{}, [&](auto D) {
+                        constexpr int r = q * 2 + decltype(D)::value;
+                        if constexpr (r < MB)
+                            read_a(G{}, C0{}, r, cur ^ 1);
+                        else if constexpr (r < MB + NB)
+                            read_b(G{}, C0{}, r - MB, cur ^ 1);
+                        else if constexpr (r < NR2)
+                            read_b(G{}, C1{}, r - MB - NB, cur ^ 1);
+                    });
+                } else if constexpr (q < RS2 + LS) {
+                    if (!Y3_ABL(1))
+                        y3_for_each_ic(std::make_integer_sequence<int, LPS>{}, [&](auto D) {
+                            constexpr int e = (q - RS2) * LPS + decltype(D)::value;
+                            if constexpr (e < NW) gload_one(nxt, G{}, std::integral_constant<int, e>{});
+                        });
+                } else if constexpr (q == RS2 + LS) {
+                    nxt = soff_prep(knext);       // the scalar arithmetic of the NEXT step's loads
+                }
+            }
+        };
+        auto step = [&](auto P, int ks) {      // P = ks & 1: LDS buffer and fragment set of tile ks
+            constexpr int cur = decltype(P)::value;
+            knext = kbeg + (ks + 4) * BK;
+            y3_for_each_ic(std::make_integer_sequence<int, NM>{}, [&](auto Mi) {
+                constexpr int m = decltype(Mi)::value;
+                constexpr int g = m / NMG, i = (m % NMG) / NB, j = m % NB;
+                constexpr int pa = g < 3 ? 0 : (g < 5 ? 1 : 2), pb = g < 3 ? g : (g == 3 ? 0 : (g == 4 ? 1 : 0));
+                if constexpr (m == SB) {
+                    if (!Y3_ABL(4)) y3_lds_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[cur][pa][i], FB[cur][pb][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                slot(Mi, P);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (RS2 + LS >= SP) nxt = soff_prep(knext);
+        };
+        gload(kbeg, C0{});
+        split_store_all(C0{}, 0);
+        __syncthreads();
+        Y3_TSTAMP(1);
+        // (pinned: issued the other way round -- the scheduler is free to -- the set the loop consumes first is the YOUNGER one and
+        // the loop's first wait becomes vmcnt(0) instead of "all but the newest tile")
+        __builtin_amdgcn_sched_barrier(0);
+        gload(kbeg + BK, C1{});
+        __builtin_amdgcn_sched_barrier(0);
+        gload(kbeg + 2 * BK, C0{});
+        __builtin_amdgcn_sched_barrier(0);
+        nxt = soff_prep(kbeg + 3 * BK);      // offsets of the loads issued in step 0 (tile 3)
+#pragma unroll
+        for (int i = 0; i < MB; ++i) read_a(C0{}, C0{}, i, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            read_b(C0{}, C0{}, j, 0);
+            read_b(C0{}, C1{}, j, 0);
+        }
+        // Uniform steps, two per iteration (buffer and register set are compile-time indices); an odd step count is padded with one
+        // dead step (all-zero operands), and the stores, barrier and reads of the last step serve a tile nobody multiplies.
+        for (int ks = 0; ks < nk; ks += 2) {
+            step(C0{}, ks);
+            step(C1{}, ks + 1);
+        }
+    }
+    Y3_TSTAMP(2);
+    conv_fast_finish<BM, BN, WM, WN, DENSE, BNS>(p, fw, acc, red);
+}
+
+// registers: two waves per SIMD (64 accumulators + 56 fragment + 32 staging registers per lane)
+template <int BM, int BN, int WM, int WN, bool DENSE, bool BNS>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3_kernel(const FastArgs p) {
+    conv_x3_body<BM, BN, WM, WN, DENSE, BNS>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+template <int BM, int BN, int WM, int WN>
+static void x3_launch_tile(const FastArgs& p, bool dense, int grid, hipStream_t st) {
+    const dim3 g(grid), b(64 * WM * WN);
+    if (p.bn_a)
+        hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WM, WN, true, true>), g, b, 0, st, p);
+    else if (dense)
+        hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WM, WN, true, false>), g, b, 0, st, p);
+    else
+        hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WM, WN, false, false>), g, b, 0, st, p);
+}
+
+// Tiles this file is built for (conv.hip plans with them): false if (bm, bn) is not one of them.
+bool y3_x3_tile_ok(int bm, int bn) { return bm == 128 && (bn == 128 || bn == 64); }
+
+bool y3_x3_launch(const FastArgs& p, int bm, int bn, bool dense, int grid, hipStream_t st) {
+    if (bm == 128 && bn == 128)
+        x3_launch_tile<128, 128, 2, 2>(p, dense, grid, st);
+    else if (bm == 128 && bn == 64)
+        x3_launch_tile<128, 64, 2, 1>(p, dense, grid, st);
+    else
+        return false;
+    return true;
+}

@@ -45,6 +45,11 @@ SIGNATURES = {
     'y3_conv2d_stats_tiles': (i32, [i32, i32, i32, i32]),
     'y3_conv2d_fwd_workspace': (sz, [i32, i32, i32, i32]),
     'y3_conv2d_dgrad': (i32, [TP, fp, i32, i32, TP, u32, vp, sz, vp]),
+    'y3_conv2d_stats_tiles_x': (i32, [i32, i32, i32, i32, u32]),
+    'y3_conv2d_fwd_workspace_x': (sz, [i32, i32, i32, i32, u32]),
+    'y3_conv2d_x3_ok': (i32, [i32, i32, i32, i32]),
+    'y3_conv2d_dgrad_workspace_x': (sz, [TP, i32, i32, TP, u32]),
+    'y3_conv2d_dgrad_bn_tiles_x': (i32, [TP, i32, i32, TP, u32]),
     'y3_conv2d_dgrad_workspace': (sz, [TP, i32, i32, TP]),
     'y3_conv2d_dgrad_bn': (i32, [TP, fp, i32, i32, TP, u32, TP, fp, vp, sz, vp]),
     'y3_conv2d_dgrad_bn_tiles': (i32, [TP, i32, i32, TP]),
@@ -104,6 +109,7 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 EPI_LRELU = 1
 EPI_ACCUM = 2
+CONV_X3 = 4      # Y3_CONV_X3: fp32 arithmetic as three bf16 pieces per operand (conv_x3.hip); the weight operand changes layout
 
 
 def check(rc, what=''):

@@ -27,7 +27,7 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) and os.path.exists(CL
 def _build(out_dir, dev):
     exe = os.path.join(out_dir, 'planner_sweep_dev' if dev else 'planner_sweep')
     objs = []
-    for src in ('conv.hip', 'core.hip'):
+    for src in ('conv.hip', 'conv_x3.hip', 'core.hip'):
         obj = os.path.join(out_dir, src.replace('.hip', '_dev.o' if dev else '.o'))
         subprocess.check_call([HIPCC, '-O1', '-g', '-std=c++17', '--cuda-host-only', '-ffp-contract=off', '-Wno-unused-function'] + SAN +
                               (['-DY3_DEV'] if dev else []) + ['-I', os.path.join(ROOT, 'include'), '-c', os.path.join(CSRC, src), '-o', obj])

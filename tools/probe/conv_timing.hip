@@ -3,8 +3,11 @@
 // XCC_ID, s_memrealtime at both ends) and prints the distributions, the workgroups per CU and the clock the chip held.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DY3_TIMING -I include -I object-detection-yolov3_amd/csrc \
 //         tools/probe/conv_timing.hip object-detection-yolov3_amd/csrc/core.hip -o tools/probe/conv_timing
-//   tools/probe/conv_timing [n h cin cout k]        (forward, stride 1; env Y3_TILE / Y3_PIPE / Y3_RSPLIT apply)
+//   tools/probe/conv_timing [n h cin cout k [x3]]   (forward, stride 1; x3 = 1: the Y3_CONV_X3 kernel; env Y3_TILE / Y3_RSPLIT / Y3_ABL apply)
+// The stamped launch is the last of 200 back-to-back stamped launches, so the clock it reports is the clock the chip HOLDS under
+// this kernel (and under the ablation Y3_ABL selects), not the clock of a first launch on an idle chip.
 #include "../../object-detection-yolov3_amd/csrc/conv.hip"
+#include "../../object-detection-yolov3_amd/csrc/conv_x3.hip"
 #include <algorithm>
 #include <cstdio>
 #include <map>
@@ -13,6 +16,7 @@
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 8, h = argc > 2 ? atoi(argv[2]) : 52, w = h, cin = argc > 3 ? atoi(argv[3]) : 128,
               cout = argc > 4 ? atoi(argv[4]) : 256, k = argc > 5 ? atoi(argv[5]) : 3;
+    const unsigned x3 = (argc > 6 && atoi(argv[6])) ? Y3_CONV_X3 : 0u;
     const size_t xs = (size_t)n * h * w * cin, ws = (size_t)k * k * cout * cin, ys = (size_t)n * h * w * cout;
     std::vector<float> hx(xs), hw(ws);
     unsigned seed = 1;
@@ -22,7 +26,7 @@ int main(int argc, char** argv) {
     float *dx, *dw, *dy, *db, *dstats;
     void* dws;
     unsigned long long* dt;
-    const size_t wsb = y3_conv2d_fwd_workspace(n * h * w, cin, k, cout) + 16;
+    const size_t wsb = y3_conv2d_fwd_workspace_x(n * h * w, cin, k, cout, x3) + 16;
     hipMalloc(&dx, xs * 4); hipMalloc(&dw, ws * 4); hipMalloc(&dy, ys * 4); hipMalloc(&db, cout * 4);
     hipMalloc(&dstats, (size_t)n * h * w / 16 * cout * 4 + 65536); hipMalloc(&dws, wsb);
     hipMemset(dws, 0, wsb);
@@ -30,7 +34,7 @@ int main(int argc, char** argv) {
     hipMemcpy(dw, hw.data(), ws * 4, hipMemcpyHostToDevice);
     hipMemset(db, 0, cout * 4);
     y3_tensor src{dx, n, h, w, cin, cin}, dst{dy, n, h, w, cout, cout};
-    auto run = [&]() { return y3_conv2d_fwd(&src, dw, db, k, 1, &dst, Y3_EPI_LRELU, 0.2f, nullptr, nullptr, nullptr, dstats, dws, wsb, nullptr); };
+    auto run = [&]() { return y3_conv2d_fwd(&src, dw, db, k, 1, &dst, Y3_EPI_LRELU | x3, 0.2f, nullptr, nullptr, nullptr, dstats, dws, wsb, nullptr); };
     if (run() != 0) { printf("launch failed: %s\n", y3_last_error()); return 1; }
     for (int i = 0; i < 20; ++i) run();
     hipDeviceSynchronize();
@@ -43,13 +47,13 @@ int main(int argc, char** argv) {
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     const double flop = 2.0 * n * h * w * k * k * cin * cout;
-    printf("layer %dx%dx%d %d->%d k%d: %.1f us per launch = %.1f TFLOP/s (stamps off)\n", n, h, w, cin, cout, k, ms * 50.f, flop / (ms * 50e-6) / 1e12);
+    printf("layer %dx%dx%d %d->%d k%d%s: %.1f us per launch = %.1f TFLOP/s (stamps off)\n", n, h, w, cin, cout, k, x3 ? " x3" : "", ms * 50.f, flop / (ms * 50e-6) / 1e12);
     const int maxwg = 1 << 16;
     hipMalloc(&dt, (size_t)maxwg * 8 * 8);
     hipMemset(dt, 0, (size_t)maxwg * 8 * 8);
     const int abl = getenv("Y3_ABL") ? atoi(getenv("Y3_ABL")) : 0;     // ablation (results become wrong, timing stays meaningful)
     hipMemcpyToSymbol(HIP_SYMBOL(y3_abl_dev), &abl, sizeof(abl));
-    if (abl) printf("ablation mask %d (1 = no global loads in the K loop, 2 = no LDS stores, 4 = no barrier)\n", abl);
+    if (abl) printf("ablation mask %d (1 = no global loads in the K loop, 2 = no LDS stores (x3: no split either), 4 = no barrier, 8 = split-K slabs stored with the default cache policy instead of sc1)\n", abl);
     {   // the whole launch under the ablation, stamps still off (the buffer pointer is set below)
         for (int i = 0; i < 5; ++i) run();
         hipDeviceSynchronize();
@@ -61,6 +65,8 @@ int main(int argc, char** argv) {
         printf("launch under ablation %d: %.1f us (stamps off)\n", abl, ms * 50.f);
     }
     hipMemcpyToSymbol(HIP_SYMBOL(y3_timing_buf), &dt, sizeof(dt));
+    for (int i = 0; i < 200; ++i) run();      // sustained load: the stamps of the last launch are the ones read back
+    hipMemsetAsync(dt, 0, (size_t)maxwg * 8 * 8, nullptr);      // (slices that are not last leave before their end stamp: no stale ones from earlier launches)
     run();
     hipDeviceSynchronize();
     std::vector<unsigned long long> t((size_t)maxwg * 8);
@@ -107,7 +113,8 @@ int main(int argc, char** argv) {
     printf("CUs used %zu; workgroups per CU:", per_cu.size());
     for (auto& kv : hist) printf("  %d x%d", kv.first, kv.second);
     printf("\n");
-    const double total_mfma_cycles = flop / 4096.0 * 64.0;         // SIMD-cycles of MFMA in the whole launch
+    // SIMD-cycles of MFMA in the whole launch: 4096 flop per 64 cycles (v_mfma_f32_32x32x2_f32); x3: 6 x 32768 flop-equivalents per 32 cycles each
+    const double total_mfma_cycles = x3 ? flop * 6.0 / 32768.0 * 32.0 : flop / 4096.0 * 64.0;
     printf("MFMA floor: %.0f cycles per SIMD if spread evenly over %zu CUs x 4 SIMDs\n", total_mfma_cycles / (per_cu.size() * 4.0), per_cu.size());
     return 0;
 }
