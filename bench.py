@@ -75,23 +75,50 @@ def tiled_4k(use_graph, precisions=('bf16', 'fp32')):
     return out
 
 
-def conv_flops_per_image(specs, img):
-    """2*MAC of every conv layer: (fwd, train = fwd + dgrad + wgrad, no dgrad for conv1)."""
-    fwd = 0
-    first = 0
-    sizes = []
+def conv_macs_per_image(specs, img):
+    """MACs of every conv layer for one image, creation order."""
     # replay the strides: spatial size of each layer's OUTPUT (creation order)
     seq = [1, 2, 2, 2, 4] + [4] * 4 + [8] + [8] * 16 + [16] + [16] * 16 + [32] + [32] * 8
     seq += [32] * 7 + [32] + [16] * 7 + [16] + [8] * 7
     assert len(seq) == len(specs)
-    for i, (sp, st) in enumerate(zip(specs, seq)):
-        o = (img // st) ** 2
-        mac = o * sp.k * sp.k * sp.cin * sp.cout
-        fwd += 2 * mac
-        if i == 0:
-            first = 2 * mac
-        sizes.append(mac)
-    return fwd, 3 * fwd - first
+    return [(img // st) ** 2 * sp.k * sp.k * sp.cin * sp.cout for sp, st in zip(specs, seq)]
+
+
+def conv_flops_per_image(specs, img):
+    """2*MAC of every conv layer: (fwd, train = fwd + dgrad + wgrad, no dgrad for conv1)."""
+    macs = conv_macs_per_image(specs, img)
+    fwd = 2 * sum(macs)
+    return fwd, 3 * fwd - 2 * macs[0]
+
+
+def measure_train(yolo, strategy, inputs, steps, warmup, barrier):
+    """W untimed + K timed steps between barriers: seconds for the K steps, last loss."""
+    loss = None
+    for _ in range(warmup):
+        loss = yolo.dist_train_step(strategy, inputs)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = yolo.dist_train_step(strategy, inputs)
+    barrier()
+    return time.perf_counter() - t0, loss
+
+
+def conv_family_roofline(yolo, plan, busy_s):
+    """Work of one step's conv launches by the matrix instruction they issue, and the fraction of the matrix pipe's peak
+    the family reaches over its busy time.  Launches with Y3_CONV_X3 (conv_x3.hip) issue SIX v_mfma_f32_32x32x16_bf16 products per
+    fp32 product: their work counts as 6 x algorithmic FLOPs against the dense bf16 peak (2 500 TFLOP/s) -- the peak of the
+    instruction actually issued (VERDICT r3 ruling); the others issue v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s).
+    frac = (time the launches would take at those peaks) / (busy time of the family)."""
+    macs = conv_macs_per_image(yolo.specs, IMG)
+    total = (3 * 2 * sum(macs) - 2 * macs[0]) * BATCH
+    x3 = 2 * BATCH * (sum(macs[i] for i in plan.x3_fwd) + sum(macs[i] for i in plan.x3_dgrad) + sum(macs[i] for i in getattr(plan, 'x3_wgrad', [])))
+    f32 = total - x3
+    t_peak = (6.0 * x3 / (BF16_MFMA_PEAK_TFLOPS * 1e12)) + f32 / (FP32_MFMA_PEAK_TFLOPS * 1e12)
+    return {'flops_per_step': total, 'flops_x3_path': x3, 'flops_f32_mfma_path': f32, 'frac': t_peak / busy_s,
+            'achieved_bf16_equivalent': (6.0 * x3 + f32 * BF16_MFMA_PEAK_TFLOPS / FP32_MFMA_PEAK_TFLOPS) / busy_s / 1e12,
+            'algorithmic_tflops': total / busy_s / 1e12,
+            'launches_x3': {'fwd': len(plan.x3_fwd), 'dgrad': len(plan.x3_dgrad), 'wgrad': len(getattr(plan, 'x3_wgrad', []))}}
 
 
 def synth_labels(rng, n):
@@ -264,6 +291,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay the training step as one HIP graph (single stream) instead of host launches with the kernel gradients on a second stream')
     ap.add_argument('--no-graph', action='store_true', help='(default now; kept for older command lines)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-f32-reference', action='store_true', help='skip the second training measurement on the plain fp32-MFMA path')
     ap.add_argument('--no-tiled', action='store_true', help='skip the tiled 4k x 4k inference measurement (BASELINE.json configs[4])')
     ap.add_argument('--tiled-only', action='store_true', help='(internal) run only the tiled 4k x 4k measurement and print its JSON: the full bench runs it in a process of its own')
     ap.add_argument('--no-inference', action='store_true', help='skip the secondary inference measurement (config: bs=8 fp32 predict + NMS)')
@@ -334,15 +362,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    loss = None
-    for _ in range(args.warmup):
-        loss = yolo.dist_train_step(strategy, inputs)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = yolo.dist_train_step(strategy, inputs)
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, loss = measure_train(yolo, strategy, inputs, args.steps, args.warmup, barrier)
     # host cost of one step: queue drained first, so that the figure is launch work and not back-pressure from a full queue
     # (outside the timed region; tools/host_profile.py: ~3.1 ms, i.e. the host could feed a step six times as fast)
     t1 = time.perf_counter()
@@ -384,12 +404,26 @@ def main():
     conv_s, per = timed_conv_pass(yolo, plan)
     conv_s2, per = timed_conv_pass(yolo, plan)        # second pass: caches / clocks settled
     conv_s = min(conv_s, conv_s2)
-    achieved = train_fl * BATCH / conv_s / 1e12
+    roof = conv_family_roofline(yolo, plan, conv_s)
+    # The same step on the plain path (every conv on v_mfma_f32_32x32x2_f32), measured in the same run: required beside a line whose
+    # arithmetic is the bf16-piece form (one GPU only: the reference is about the kernels, not about the collective)
+    f32_ref = None
+    if world == 1 and yolo.conv_arithmetic != 'f32' and not args.no_f32_reference:
+        yref = YoloV3(global_batch, [IMG, IMG, 3], K, ANCHORS, learning_rate=1e-4, seed=1, use_graph=use_graph, conv_arithmetic='f32')
+        dt_ref, _ = measure_train(yref, None, inputs, args.steps, args.warmup, barrier)
+        pref = yref._plan(BATCH, True)
+        timed_conv_pass(yref, pref)
+        cs_ref, _ = timed_conv_pass(yref, pref)
+        f32_ref = {'value': global_batch * args.steps / dt_ref, 'ms_per_step': dt_ref / args.steps * 1e3,
+                   'frac': train_fl * BATCH / cs_ref / 1e12 / FP32_MFMA_PEAK_TFLOPS, 'kernel_ms_per_step': cs_ref * 1e3,
+                   'note': 'same model, conv_arithmetic=f32: every conv launch on v_mfma_f32_32x32x2_f32; frac = algorithmic flops / family busy time / 157.3'}
+        del yref, pref
+        torch.cuda.empty_cache()
     # HBM-side traffic of the same kernel family comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950,
     # WRITE_SIZE; see profiles/README.md): bench.py cannot run the profiler on itself, so it reports the figure committed in
     # the SAME round as the kernels it times (profiles/rNN_traffic.json, newest first) and says which file it was
     traffic, traffic_src = None, None
-    for tag in ('r03', 'r02', 'r01'):
+    for tag in ('r04', 'r03', 'r02', 'r01'):
         try:
             with open(os.path.join(ROOT, 'profiles', '%s_traffic.json' % tag)) as fh:
                 traffic = json.load(fh).get('conv_family_hbm_bytes_per_step')
@@ -445,7 +479,10 @@ def main():
                  'decode_us': decode_us, 'decode_gbps': 2 * row_bytes / decode_us / 1e3, 'nms_us': nms_us, 'nms_gbps': row_bytes / nms_us / 1e3,
                  'decode_nms_bytes': {'rows_bytes': row_bytes, 'decode': '2 x rows (read feature maps, write rows)', 'nms': '1 x rows + keep lists',
                                       'note': '1.6 MB per launch: launch / latency bound, far below the 8 TB/s HBM peak by construction; us is the figure to compare'},
-                 'forward_tflops': fwd_fl * BATCH / t_fwd / 1e12, 'forward_frac_of_fp32_mfma_peak': fwd_fl * BATCH / t_fwd / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+                 'forward_tflops': fwd_fl * BATCH / t_fwd / 1e12, 'conv_arithmetic': yolo.conv_arithmetic, 'x3_forward_launches': len(iplan.x3_fwd),
+                 'forward_frac_of_fp32_mfma_peak': fwd_fl * BATCH / t_fwd / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                 'frac_note': 'algorithmic forward FLOPs over the whole forward + decode time against 157.3 TFLOP/s; with conv_arithmetic x3 the named launches '
+                              'run on the bf16 matrix pipe (6 products per fp32 product), so this ratio is a speed statement, not a utilisation of that peak'}
         # the same batch on the bf16 conv path (v_mfma_f32_32x32x16_bf16, fp32 accumulate / heads / decode / NMS)
         for _ in range(3):
             yolo.predict(images, precision='bf16')
@@ -494,20 +531,30 @@ def main():
             'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'f32',
+            'arithmetic': ('3xbf16 split operands, 6 partial products, fp32 accumulate (v_mfma_f32_32x32x16_bf16) on %d forward / %d data-gradient / %d kernel-gradient '
+                           'launches; v_mfma_f32_32x32x2_f32 on the others' % (roof['launches_x3']['fwd'], roof['launches_x3']['dgrad'], roof['launches_x3']['wgrad']))
+                          if roof['flops_x3_path'] else 'v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain)',
             'data': 'synthetic',
             'config': {'workload': 'train.py step (model.py:481-508): fwd + loss + bwd + Keras Adam%s, batch 8 per GPU, 416x416x3, '
-                                   'anchors [(64,384),(384,64)], 2 classes, fp32 MFMA convs' % (' + RCCL grad all-reduce' if world > 1 else ''),
+                                   'anchors [(64,384),(384,64)], 2 classes, fp32 convs on the matrix cores' % (' + RCCL grad all-reduce' if world > 1 else ''),
                        'global_batch': global_batch, 'per_gpu_batch': BATCH, 'image': [IMG, IMG, 3],
                        'launch': 'hip-graph' if use_graph else 'host launches, kernel gradients on a second stream', 'parallelism': 'dp%d' % world},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': 'conv_igemm_fast_kernel + conv_wgrad_kernel (MFMA implicit-GEMM conv fwd/dgrad/wgrad; split-K and kernel gradients of <= 8 pixel splits reduced in-kernel, the others followed by slab_reduce_kernel inside the same entry), %d entry calls/step; achieved = flops / union of their busy intervals' % sum(v[1] for v in per.values()),
-                         'peak_note': 'peak = 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz; under this load the chip holds 2.0-2.2 GHz (tools/probe/conv_timing), i.e. 131-144 TFLOP/s',
+            'roofline': {'bound': 'mfma', 'achieved': roof['achieved_bf16_equivalent'], 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': roof['frac'], 'traffic': traffic, 'traffic_source': traffic_src,
+                         'achieved_note': 'matrix-instruction work over the union of the conv family\'s busy intervals, in bf16-MFMA-equivalent TFLOP/s: launches on the '
+                                          'x3 path count 6 x their algorithmic FLOPs (six v_mfma_f32_32x32x16_bf16 products per fp32 product, peak 2 500), launches on '
+                                          'v_mfma_f32_32x32x2_f32 count their algorithmic FLOPs x 2500/157.3 (that instruction\'s peak is 157.3); frac = achieved / peak '
+                                          '= (time at the peak of the instruction each launch issues) / busy time.  NOT algorithmic FLOPs against 157.3.',
+                         'algorithmic_tflops': roof['algorithmic_tflops'], 'flops_x3_path': roof['flops_x3_path'], 'flops_f32_mfma_path': roof['flops_f32_mfma_path'],
+                         'kernel': 'conv_x3_kernel + conv_igemm_fast_kernel + conv_wgrad_kernel (MFMA implicit-GEMM conv fwd/dgrad/wgrad; split-K and kernel gradients of <= 8 pixel splits reduced in-kernel, the others followed by slab_reduce_kernel inside the same entry), %d entry calls/step' % sum(v[1] for v in per.values()),
+                         'peak_note': 'bf16 peak = 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz (dense); fp32-MFMA peak 157.3 = 64 FLOP/clk; the chip holds 1.9-2.0 GHz under the x3 kernels and 2.2-2.4 GHz under the fp32-MFMA kernels (tools/probe/conv_timing, profiles/r04_clock_ablate.txt)',
                          'flops_per_step': train_fl * BATCH, 'kernel_ms_per_step': conv_s * 1e3,
                          'by_entry_ms': {k: round(v[0] * 1e3, 3) for k, v in per.items()}},
             'step_flop_rate_tflops': train_fl * BATCH / (dt / args.steps) / 1e12,
             'final_loss': loss_val,
         }
+        if f32_ref is not None:
+            out['fp32_mfma_reference'] = f32_ref
         if infer is not None:
             out['inference_bs8_fp32'] = infer
         if infer16 is not None:

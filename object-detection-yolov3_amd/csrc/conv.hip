@@ -1033,7 +1033,7 @@ static inline int even_steps(int chunk) { return chunk + (chunk & 1); }
 static bool x3_shape_ok(int C, int Nout, int K, int ntaps) {
     return C % 16 == 0 && K % 16 == 0 && (ntaps == 1 || y3_is_pow2(C)) && Nout >= 32 && K / 16 >= 2;
 }
-static ConvPlan plan_conv_x3(int M, int Nout, int K) {
+static ConvPlan plan_conv_x3(int M, int Nout, int K, int ntaps) {
     ConvPlan pl;
     pl.t = {128, Nout <= 64 ? 64 : 128, 16};
     {
@@ -1047,21 +1047,51 @@ static ConvPlan plan_conv_x3(int M, int Nout, int K) {
     pl.chunk0 = pl.chunk1 = even_steps(nk);
     static const int want = env_int("Y3_X3_WGS", 700);
     static const int min_steps = env_int("Y3_X3_MINSTEPS", 12);
-    if (tiles <= Y3_MAX_TICKETS && tiles * 4 <= want * 3) {
+    // slices are whole units of K steps: 3x3 launches in units of 18 (two 16-channel chunks of nine taps: the patch kernel's loop
+    // body, conv_x3.hip), the others in pairs of steps
+    const int unit = ntaps == 9 ? 18 : 2;
+    static const int rsplit_on = env_int("Y3_X3_RSPLIT", 2);      // 0 off, 1 only where the uniform split does not apply, 2 preferred above 256 tiles
+    if (tiles <= Y3_MAX_TICKETS && tiles * 4 <= want * 3 && !(rsplit_on == 2 && tiles > 256)) {
         int ks = (want + tiles / 2) / tiles;
         if (ks > nk / min_steps) ks = nk / min_steps;
         if (ks > 16) ks = 16;
         if (ks > 1) {
-            pl.chunk0 = even_steps(y3_cdiv(nk, ks));
+            pl.chunk0 = y3_cdiv(y3_cdiv(nk, ks), unit) * unit;
             pl.s0 = y3_cdiv(nk, pl.chunk0);
+            if (pl.s0 <= 1) {
+                pl.s0 = 1;
+                pl.chunk0 = even_steps(nk);
+            }
+        }
+    }
+    else if (tiles <= Y3_MAX_TICKETS && tiles > 256) {
+        // more tiles than CUs but too few to balance by themselves (338 tiles: a third of the CUs would carry two): whole rounds of
+        // tiles stay whole -- no slabs for them -- and only the remainder round is cut, so that its pieces spread evenly
+        const int F = tiles / 256 * 256, R = tiles - F;
+        int best = 1;
+        double best_cost = 1.0;
+        for (int S = 2; rsplit_on && S <= 6; ++S) {
+            const int ch = y3_cdiv(y3_cdiv(nk, S), unit) * unit;
+            if (ch * S != nk || ch < min_steps) continue;             // equal slices only
+            const double cost = (double)y3_cdiv((long long)R * S, 256) / S + 0.03 * (S - 1);
+            if (cost < best_cost - 1e-9) {
+                best_cost = cost;
+                best = S;
+            }
+        }
+        if (R > 0 && best > 1) {
+            pl.f = F;
+            pl.chunk1 = nk / best;
+            pl.s1 = best;
         }
     }
     pl.stats_tiles = y3_cdiv(M, pl.t.bm);
-    const long long split_items = pl.s0 > 1 ? (long long)tiles * pl.s0 : 0;
+    const long long split_items = pl.s0 > 1 ? (long long)tiles * pl.s0 : (pl.s1 > 1 ? (long long)(tiles - pl.f) * pl.s1 : 0);
     const long long slab_bytes = split_items * pl.t.bm * pl.t.bn * 4;
     if (slab_bytes >= 0x7ff00000LL) {
-        pl.s0 = 1;
-        pl.chunk0 = even_steps(nk);
+        pl.f = tiles;
+        pl.s0 = pl.s1 = 1;
+        pl.chunk0 = pl.chunk1 = even_steps(nk);
         pl.ws_bytes = 0;
     } else {
         pl.ws_bytes = split_items > 0 ? (size_t)Y3_WS_HEADER + (size_t)slab_bytes : 0;
@@ -1069,8 +1099,8 @@ static ConvPlan plan_conv_x3(int M, int Nout, int K) {
     return pl;
 }
 // fast_ok: the launch qualifies for conv_igemm_fast_kernel (the only kernel with split-K)
-static ConvPlan plan_conv(int M, int Nout, int K, bool fast_ok, bool x3 = false) {
-    if (x3) return plan_conv_x3(M, Nout, K);
+static ConvPlan plan_conv(int M, int Nout, int K, bool fast_ok, bool x3 = false, int ntaps = 1) {
+    if (x3) return plan_conv_x3(M, Nout, K, ntaps);
     ConvPlan pl;
     pl.t = pick_tile(M, Nout);
     const int tiles = y3_cdiv(M, pl.t.bm) * y3_cdiv(Nout, pl.t.bn);
@@ -1161,12 +1191,12 @@ extern "C" int y3_conv2d_x3_ok(int m, int c, int ntaps, int nout) {
 extern "C" int y3_conv2d_stats_tiles_x(int m, int cin, int ksize, int cout, unsigned flags) {
     const int taps = ksize * ksize;
     const bool x3 = (flags & Y3_CONV_X3) && x3_shape_ok(cin, cout, taps * cin, taps);
-    return plan_conv(m, cout, taps * cin, fast_shape_ok(cin, cout, taps * cin, taps), x3).stats_tiles;
+    return plan_conv(m, cout, taps * cin, fast_shape_ok(cin, cout, taps * cin, taps), x3, taps).stats_tiles;
 }
 extern "C" size_t y3_conv2d_fwd_workspace_x(int m, int cin, int ksize, int cout, unsigned flags) {
     const int taps = ksize * ksize;
     const bool x3 = (flags & Y3_CONV_X3) && x3_shape_ok(cin, cout, taps * cin, taps);
-    return plan_conv(m, cout, taps * cin, fast_shape_ok(cin, cout, taps * cin, taps), x3).ws_bytes;
+    return plan_conv(m, cout, taps * cin, fast_shape_ok(cin, cout, taps * cin, taps), x3, taps).ws_bytes;
 }
 extern "C" int y3_conv2d_stats_tiles(int m, int cin, int ksize, int cout) { return y3_conv2d_stats_tiles_x(m, cin, ksize, cout, 0u); }
 extern "C" size_t y3_conv2d_fwd_workspace(int m, int cin, int ksize, int cout) { return y3_conv2d_fwd_workspace_x(m, cin, ksize, cout, 0u); }
@@ -1308,7 +1338,7 @@ static int launch_igemm(const ConvArgs& a, void* workspace, size_t workspace_byt
         return Y3_EINVAL;
     }
     const bool fast_ok = x3 || fast_shape_ok(p.C, p.Nout, p.K, ntaps);
-    ConvPlan pl = plan_conv(p.M, p.Nout, p.K, fast_ok, x3);
+    ConvPlan pl = plan_conv(p.M, p.Nout, p.K, fast_ok, x3, ntaps);
     if (pl.ws_bytes > 0 && (workspace == nullptr || workspace_bytes < pl.ws_bytes)) {  // no room for slabs: whole tiles
         pl.f = pl.tiles;
         pl.s0 = pl.s1 = 1;
@@ -1470,7 +1500,7 @@ extern "C" size_t y3_conv2d_dgrad_workspace_x(const y3_tensor* ddst, int ksize, 
     if (stride == 1) {
         const int K = taps * ddst->c;
         const bool x3 = (flags & Y3_CONV_X3) && x3_shape_ok(ddst->c, dsrc->c, K, taps);
-        return plan_conv(dsrc->n * dsrc->h * dsrc->w, dsrc->c, K, fast_shape_ok(ddst->c, dsrc->c, K, taps), x3).ws_bytes;
+        return plan_conv(dsrc->n * dsrc->h * dsrc->w, dsrc->c, K, fast_shape_ok(ddst->c, dsrc->c, K, taps), x3, taps).ws_bytes;
     }
     size_t best = 0;
     for (int nt = 1; nt <= 4; nt *= 2) {  // parity classes carry 1, 2, 2 and 4 taps of a 3x3 kernel
@@ -1573,7 +1603,7 @@ extern "C" int y3_conv2d_dgrad_bn_tiles_x(const y3_tensor* ddst, int ksize, int 
     const int taps = ksize * ksize, K = taps * ddst->c, M = dsrc->n * dsrc->h * dsrc->w;
     const bool x3 = dgrad_x3(flags, ddst, ksize, stride, dsrc);
     if (!x3 && !fast_shape_ok(ddst->c, dsrc->c, K, taps)) return 0;
-    const ConvPlan pl = plan_conv(M, dsrc->c, K, true, x3);
+    const ConvPlan pl = plan_conv(M, dsrc->c, K, true, x3, taps);
     if (pl.t.bk != 16) return 0;
     // the launch itself must be accepted too (2 GiB buffer limits, tap grid): dry run of the argument builder
     int ok = 0;

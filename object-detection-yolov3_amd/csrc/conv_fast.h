@@ -174,7 +174,7 @@ __device__ __forceinline__ FastWork conv_fast_decode(const FastArgs& p, const in
 // Everything after the K loop: the split-K hand-off (slices of a tile park their raw accumulators, the last arriver sums them
 // in slice order) and the epilogue (bias, leaky-relu, BatchNorm statistics / folded affine, residual, accumulate, stores).
 // `red`: LDS for the column sums, [2 or 6][WM][BN] floats (BNS kernels pass their A stage, dead after the loop).
-template <int BM, int BN, int WM, int WN, bool DENSE, bool BNS>
+template <int BM, int BN, int WM, int WN, bool DENSE, bool BNS, bool PEEK = false>
 __device__ __forceinline__ void conv_fast_finish(const FastArgs& p, const FastWork& w, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float (*red)[WM][BN]) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
@@ -189,39 +189,26 @@ __device__ __forceinline__ void conv_fast_finish(const FastArgs& p, const FastWo
         // stored sc1 (written through, no L2 write-back fence needed) and loaded sc1, every storing wave drains vmcnt before the
         // workgroup barrier, ONE lane then adds to the tile's ticket with an agent-scope atomic and the workgroup whose add
         // came last (told by the value returned) loads after a second barrier.
+        // PEEK (the x3 kernels): before parking anything a slice LOOKS at the ticket (one sc1 load -- the "poll of that counter"
+        // form of the same table row).  If the other nz - 1 slices have all arrived it is the last one for certain: it neither
+        // stores nor re-reads its own 64 KB but sums the others' slabs around its registers, IN SLICE ORDER as always (slabs
+        // 0 .. kz-1, then its own accumulators, then kz+1 .. nz-1: the sum is bit for bit the one the ticket path produces,
+        // whichever slice ends up last).  Otherwise it parks and takes a ticket as before.  The last finisher of a tile -- the one
+        // the launch waits for -- thus skips a 64 KB write-through store, its drain and a barrier, and 1 / nz of the slab bytes
+        // never exist (nz = 2: half).
         constexpr int R4 = MB * NB * 4;
         const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, 0x7ffffff0, 0x00020000);
         const unsigned item_bytes = (unsigned)(R4 * THREADS * 16);
-        {
-            const unsigned base = (unsigned)(bid0 - p.sk_slab0) * item_bytes + (unsigned)tid * 16u;
-#pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        f32x4 v = {acc[i][j][4 * r], acc[i][j][4 * r + 1], acc[i][j][4 * r + 2], acc[i][j][4 * r + 3]};
-                        if (Y3_ABL(8))      // probe only: default cache policy (the hand-off is then not guaranteed; timing / clock experiment)
-                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, base, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 0);
-                        else
-                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, base, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
-                    }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
         int* flag = reinterpret_cast<int*>(&red[0][0][0]);
-        if (tid == 0) {
-            const int old = __hip_atomic_fetch_add(p.tickets + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = old == nz - 1;
-            if (last) __hip_atomic_store(p.tickets + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = last;
+        bool sure_last = false;
+        if constexpr (PEEK) {
+            if (tid == 0) *flag = __hip_atomic_load(p.tickets + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nz - 1 ? 1 : 0;
+            __syncthreads();
+            sure_last = *flag != 0;
+            __syncthreads();      // (flag is written again below)
         }
-        __syncthreads();
-        if (*flag == 0) return;
-        __syncthreads();  // `red` is reused by the statistics below
         const unsigned first = (unsigned)(bid0 - kz - p.sk_slab0) * item_bytes + (unsigned)tid * 16u;   // slice 0 of this tile
-#pragma unroll 1
-        for (int z = 0; z < nz; ++z) {
+        auto add_slab = [&](f32x16 (&dst)[MB][NB], int z, bool init) {
             const unsigned base = first + (unsigned)z * item_bytes;
 #pragma unroll
             for (int i = 0; i < MB; ++i)
@@ -231,8 +218,53 @@ __device__ __forceinline__ void conv_fast_finish(const FastArgs& p, const FastWo
                     for (int r = 0; r < 4; ++r) {
                         const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, base, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[i][j][4 * r + e] = z == 0 ? v[e] : acc[i][j][4 * r + e] + v[e];
+                        for (int e = 0; e < 4; ++e) dst[i][j][4 * r + e] = init ? v[e] : dst[i][j][4 * r + e] + v[e];
                     }
+        };
+        if (PEEK && sure_last) {
+            if (tid == 0) __hip_atomic_store(p.tickets + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (kz > 0) {
+                f32x16 head[MB][NB];
+#pragma unroll 1
+                for (int z = 0; z < kz; ++z) add_slab(head, z, z == 0);
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = head[i][j][r] + acc[i][j][r];
+            }
+#pragma unroll 1
+            for (int z = kz + 1; z < nz; ++z) add_slab(acc, z, false);
+        } else {
+            {
+                const unsigned base = (unsigned)(bid0 - p.sk_slab0) * item_bytes + (unsigned)tid * 16u;
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            f32x4 v = {acc[i][j][4 * r], acc[i][j][4 * r + 1], acc[i][j][4 * r + 2], acc[i][j][4 * r + 3]};
+                            if (Y3_ABL(8))      // probe only: default cache policy (the hand-off is then not guaranteed; timing / clock experiment)
+                                __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, base, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 0);
+                            else
+                                __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, base, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
+                        }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const int old = __hip_atomic_fetch_add(p.tickets + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == nz - 1;
+                if (last) __hip_atomic_store(p.tickets + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = last;
+            }
+            __syncthreads();
+            if (*flag == 0) return;
+            __syncthreads();  // `red` is reused by the statistics below
+#pragma unroll 1
+            for (int z = 0; z < nz; ++z) add_slab(acc, z, z == 0);
         }
     }
 

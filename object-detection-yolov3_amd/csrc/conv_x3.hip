@@ -315,7 +315,321 @@ __device__ __forceinline__ void conv_x3_body(const FastArgs& p, const int braw, 
         }
     }
     Y3_TSTAMP(2);
-    conv_fast_finish<BM, BN, WM, WN, DENSE, BNS>(p, fw, acc, red);
+    conv_fast_finish<BM, BN, WM, WN, DENSE, BNS, true>(p, fw, acc, red);
+}
+
+// ---------------------------------------------------------------------------
+// The same arithmetic for the stride-1 3x3 layers with the A operand staged as a PATCH ("x3p").  An implicit-GEMM loop over
+// (tap, channel) fetches and splits every activation nine times, once per tap; conv_x3_body above spends more time on its
+// global loads and on the split than on its matrix instructions (probe: 97.8 us per launch, 79.6 without the loads, 86.8 without
+// split + stores, 37 us of MFMA at the clock the chip holds).  Here the K loop runs channel chunk outermost: the 16 channels of
+// a chunk are staged ONCE for all pixels the tile's nine taps touch -- the BM output pixels plus W + 1 pixels of halo on either
+// side in the flattened (image, row, column) order, <= Y3_X3P_ROWS rows -- and the nine taps of the chunk read their A
+// fragments from that one patch at a row shift of dh * W + dw.  Taps that fall outside the image (zero padding; rows of
+// another image) are a per-lane bit test that points the fragment read at an all-zero row.  Per K step the workgroup then
+// loads and splits only its weight tile; the activations cost 4 loads and 88 vector instructions per thread per NINE steps.
+// The loop body is 18 steps (two chunks: LDS buffer, register set and tap are compile-time indices).
+// ---------------------------------------------------------------------------
+#define Y3_X3P_ROWS 240      // patch rows held in LDS: BM + 2 * (W + 1) <= 240, i.e. image widths up to 55 with 128-row tiles
+
+struct X3Pk {
+    unsigned p0, p1;
+};
+// one of the four sub-steps of splitting 4 consecutive k (16 bytes of fp32) into the three piece planes (8-byte slots d0 / d1 / d2)
+template <int SUB>
+__device__ __forceinline__ void x3_split_sub(f32x4& v, X3Pk& st, unsigned short* d0, unsigned short* d1, unsigned short* d2) {
+    if constexpr (SUB == 0) {
+        st.p0 = x3_pk(v[0], v[1]);
+        st.p1 = x3_pk(v[2], v[3]);
+        *reinterpret_cast<uint2*>(d0) = make_uint2(st.p0, st.p1);
+        v[0] -= x3_lo(st.p0);
+        v[1] -= x3_hi(st.p0);
+    } else if constexpr (SUB == 1) {
+        v[2] -= x3_lo(st.p1);
+        v[3] -= x3_hi(st.p1);
+        st.p0 = x3_pk(v[0], v[1]);
+        st.p1 = x3_pk(v[2], v[3]);
+        *reinterpret_cast<uint2*>(d1) = make_uint2(st.p0, st.p1);
+    } else if constexpr (SUB == 2) {
+        v[0] -= x3_lo(st.p0);
+        v[1] -= x3_hi(st.p0);
+        v[2] -= x3_lo(st.p1);
+    } else {
+        v[3] -= x3_hi(st.p1);
+        *reinterpret_cast<uint2*>(d2) = make_uint2(x3_pk(v[0], v[1]), x3_pk(v[2], v[3]));
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool BNS>
+__device__ __forceinline__ void conv_x3p_body(const FastArgs& p, const int braw, const int grid) {
+    constexpr int BK = 16, KV = 4, NT = 9;
+    constexpr int THREADS = 64 * WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
+    constexpr int PR = Y3_X3P_ROWS;
+    constexpr int A4 = (PR * KV + THREADS - 1) / THREADS;      // patch loads per thread and chunk
+    constexpr int B_LOADS = BN * KV / THREADS;
+    static_assert((BN * KV) % THREADS == 0 && TM % 32 == 0 && TN % 32 == 0, "tile shape");
+    constexpr int AHP = (PR + 1) * 8 + 32;      // u16 per k half of a patch plane: PR rows, the all-zero row (index PR), 64 bytes of pad
+    constexpr int AP = 6 * AHP;                 // one patch buffer: 3 pieces x 2 k halves
+    constexpr int BH = BN * 8 + 32, B3 = 6 * BH;
+    constexpr int RED = (BNS ? 6 : 2) * WM * BN;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * AP + 2 * B3 + 2 * RED];     // [patch 0][patch 1][B 0][B 1][column sums]
+    constexpr int BOFF = 2 * AP;
+    float (*red)[WM][BN] = reinterpret_cast<float (*)[WM][BN]>(&lds[2 * AP + 2 * B3]);
+
+    Y3_TSTAMP(0);
+    Y3_ABL_INIT();
+#ifdef Y3_TIMING
+    if (y3_timing_buf && threadIdx.x == 0) {
+        y3_timing_buf[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+        y3_timing_buf[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+        y3_timing_buf[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    const FastWork fw = conv_fast_decode<BM, BN, WM, WN, BK>(p, braw, grid);
+    const int tid = fw.tid, l31 = fw.l31, lh = fw.lh, wm = fw.wm, wn = fw.wn;
+    const int m0 = fw.m0, n0 = fw.n0, kbeg = fw.kbeg, kend = fw.kend;
+    const int ohw = fw.ohw, OW = fw.OW, aM = fw.aM, aH = fw.aH, aW = fw.aW, src_ld = fw.src_ld, Nout = fw.Nout;
+    const Y3Div dv_ohw = fw.dv_ohw, dv_ow = fw.dv_ow;
+
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.wt_bytes, 0x00020000);
+
+    // patch row r <-> input pixel m0 - halo + r of the flattened (image, row, column) index (stride 1, SAME: output pixel m reads
+    // input pixels m + dh * W + dw); p.src is biased by -halo pixels (make_fast), rows before the tensor / past its end read zeros
+    const int halo = aW + 1;
+    const int a_kv = tid % KV;
+    unsigned pa_voff[A4];
+#pragma unroll
+    for (int j = 0; j < A4; ++j) {
+        const int row = (tid + j * THREADS) / KV;
+        const int q = m0 - halo + row;
+        const bool ok = row < BM + 2 * halo && row < PR && q >= 0 && q < aM;
+        pa_voff[j] = ok ? (unsigned)((q + halo) * src_ld + a_kv * 4) * 4u : Y3_OOB;
+    }
+    unsigned b_voff[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int n = n0 + (tid + i * THREADS) / KV;
+        b_voff[i] = n < Nout ? (unsigned)(n * p.Cper + a_kv * 4) * 4u : Y3_OOB;
+    }
+    // per-tap scalars: row shift of the patch, and the byte offset of the tap's block of the K-contiguous kernel copy
+    int s_shift[NT];
+    unsigned s_wtap[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        s_shift[t] = (p.tap_dh[t] * aW + p.tap_dw[t]) * 8;                                   // u16 units (8 per row)
+        s_wtap[t] = (unsigned)((p.tg_w0 + (t / 3) * p.tg_wy + (t % 3) * p.tg_wx) * p.Nout) * 4u;
+    }
+    // which taps of this lane's output pixels stay inside the image (bit t), per 32-row block
+    unsigned fmask[MB];
+    int a_fr0[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int m = m0 + wm * TM + i * 32 + l31;
+        const bool ok = m < aM;
+        const int mm = ok ? m : 0;
+        const int n = y3_div(mm, dv_ohw);
+        const int r = mm - n * ohw;
+        const int oh = y3_div(r, dv_ow);
+        const int ow = r - oh * OW;
+        unsigned msk = 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int ih = oh + p.tap_dh[t], iw = ow + p.tap_dw[t];
+            if (ok && (unsigned)ih < (unsigned)aH && (unsigned)iw < (unsigned)aW) msk |= 1u << t;
+        }
+        fmask[i] = msk;
+        a_fr0[i] = lh * AHP + (halo + wm * TM + i * 32 + l31) * 8;
+    }
+    const int zero_fr = lh * AHP + PR * 8;
+    const int pa_st = (a_kv >> 1) * AHP + (tid / KV) * 8 + (a_kv & 1) * 4;
+    const int b_st = (a_kv >> 1) * BH + (tid / KV) * 8 + (a_kv & 1) * 4;
+    const int b_fr = lh * BH + (wn * TN + l31) * 8;
+
+    // K bookkeeping: a slice covers whole chunks; step s of the slice is (chunk c0 + s / 9, tap s % 9)
+    const int nk = (kend - kbeg) / BK;            // multiple of 18 (host)
+    const int c0 = (kbeg / BK) / NT;
+    const int nchunks = nk / NT;
+
+    // Staging registers.  A K step is only 768 cycles of MFMA per wave, so a tile loaded "two steps ahead" has about one step
+    // (~1 us) to arrive -- less than an L2 round trip under load, and the loop stood at its vmcnt waits (probe: 83 k cycles per
+    // workgroup against 56 k with the loads ablated).  The weight tiles therefore go through a ring of THREE sets (tile s in set
+    // s % 3, loaded in step s - 4, stored in step s - 1: two full steps in flight), and the patch of the next chunk, loaded at
+    // tap 0, is not touched before tap 3.
+    f32x4 rp[A4];                                  // patch staging (one set: loaded at tap 0 of a chunk, stored over its taps 3..8)
+    f32x4 rb[3][B_LOADS];
+    X3Pk pk_a = {0, 0}, pk_b = {0, 0};
+    auto patch_load = [&](int chunk_rel) {         // chunk c0 + chunk_rel; beyond the slice: dead (zeros)
+        const bool live = chunk_rel < nchunks;
+        const unsigned soff = (unsigned)((c0 + (live ? chunk_rel : 0)) * BK) * 4u;
+#pragma unroll
+        for (int j = 0; j < A4; ++j) rp[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, live ? pa_voff[j] : Y3_OOB, soff, 0);
+    };
+    auto patch_load_one = [&](auto J, int chunk_rel) {
+        constexpr int j = decltype(J)::value;
+        const bool live = chunk_rel < nchunks;
+        const unsigned soff = (unsigned)((c0 + (live ? chunk_rel : 0)) * BK) * 4u;
+        rp[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, live ? pa_voff[j] : Y3_OOB, soff, 0);
+    };
+    auto patch_sub = [&](auto E, int pb) {         // sub-step E (0 .. 4 * A4 - 1) of the patch in rp -> patch buffer pb
+        constexpr int e = decltype(E)::value, j = e / 4, sub = e % 4;
+        const int row = (tid + j * THREADS) / KV;
+        if (A4 * THREADS <= PR * KV || row < PR) {
+            unsigned short* d = &lds[pb * AP + pa_st + j * (THREADS / KV) * 8];
+            x3_split_sub<sub>(rp[j], pk_a, d, d + 2 * AHP, d + 4 * AHP);
+        }
+    };
+    auto b_load_one = [&](auto S, auto E, int step, auto T) {      // step (relative to the slice) with compile-time tap T
+        constexpr int set = decltype(S)::value, e = decltype(E)::value, t = decltype(T)::value;
+        const bool live = step < nk;
+        const int chunk = c0 + (live ? step : 0) / NT;
+        rb[set][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[e] | (live ? 0u : Y3_OOB), s_wtap[t] + (unsigned)(chunk * BK) * 4u, 0);
+    };
+    auto b_sub = [&](auto S, auto E, int buf) {
+        constexpr int set = decltype(S)::value, e = decltype(E)::value, w = e / 4, sub = e % 4;
+        unsigned short* d = &lds[BOFF + buf * B3 + b_st + w * (THREADS / KV) * 8];
+        x3_split_sub<sub>(rb[set][w], pk_b, d, d + 2 * BH, d + 4 * BH);
+    };
+
+    y3_bf16x8 FA[2][3][MB], FB[2][3][NB];
+    int a_addr[2][MB];                             // fragment address (u16 index inside a patch buffer, piece 0) of the step's tap, per block
+    auto set_addr = [&](auto F, auto T) {
+        constexpr int f = decltype(F)::value, t = decltype(T)::value;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) a_addr[f][i] = ((fmask[i] >> t) & 1u) ? a_fr0[i] + s_shift[t] : zero_fr;
+    };
+    auto read_a = [&](auto F, auto PC, int i, int pb) {
+        FA[decltype(F)::value][decltype(PC)::value][i] =
+            *reinterpret_cast<const y3_bf16x8*>(&lds[pb * AP + decltype(PC)::value * 2 * AHP + a_addr[decltype(F)::value][i]]);
+    };
+    auto read_b = [&](auto F, auto PC, int j, int buf) {
+        FB[decltype(F)::value][decltype(PC)::value][j] =
+            *reinterpret_cast<const y3_bf16x8*>(&lds[BOFF + buf * B3 + decltype(PC)::value * 2 * BH + b_fr + j * 32 * 8]);
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    {
+        constexpr int NMG = MB * NB, NM = 6 * NMG, SB = Y3_X3_GB * NMG, SP = NM - SB;
+        constexpr int NR1 = NB + MB + MB;          // reads in front of the barrier: B2, A1, A2
+        constexpr int NSB = B_LOADS * 4;           // weight sub-steps per step
+        constexpr int NSA = A4 * 4;                // patch sub-steps per chunk, spread over taps TA0 .. 8
+        constexpr int TA0 = 3;
+        constexpr int SA_PER = (NSA + NT - TA0 - 1) / (NT - TA0);
+        constexpr int NR2 = MB + NB + NB, RS2 = (NR2 + 1) / 2;
+        static_assert(NR1 <= SB && RS2 + B_LOADS + (A4 + 1) / 2 <= SP, "not enough MFMA slots for the events of a K step");
+        // step U of the 18-step body (two chunks), chunk pair starting at relative chunk cp
+        auto step = [&](auto U, int cp) {
+            constexpr int u = decltype(U)::value, cr = u / NT, t = u % NT, cur = u & 1;
+            constexpr int un = (u + 1) % (2 * NT), crn = un / NT, tn = un % NT;          // the next step: patch buffer, tap
+            using F = std::integral_constant<int, cur>;
+            using G = std::integral_constant<int, cur ^ 1>;
+            using RS = std::integral_constant<int, (u + 1) % 3>;      // weight register set stored (tile u + 1) and reloaded (tile u + 4) in this step
+            const int srel = cp * NT + u;           // step relative to the slice
+            y3_for_each_ic(std::make_integer_sequence<int, NM>{}, [&](auto Mi) {
+                constexpr int m = decltype(Mi)::value;
+                constexpr int g = m / NMG, i = (m % NMG) / NB, j = m % NB;
+                constexpr int pa = g < 3 ? 0 : (g < 5 ? 1 : 2), pb = g < 3 ? g : (g == 3 ? 0 : (g == 4 ? 1 : 0));
+                if constexpr (m == SB) {
+                    if (!Y3_ABL(4)) y3_lds_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[cur][pa][i], FB[cur][pb][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (m < SB) {
+                    if constexpr (m < NB)
+                        read_b(F{}, C2{}, m, cur);
+                    else if constexpr (m < NB + MB)
+                        read_a(F{}, C1{}, m - NB, cr);
+                    else if constexpr (m < NR1)
+                        read_a(F{}, C2{}, m - NB - MB, cr);
+                    // weight tile of the next step: split + store
+                    constexpr int s0 = m * NSB / SB, s1 = (m + 1) * NSB / SB;
+                    if (!Y3_ABL(2))
+                        y3_for_each_ic(std::make_integer_sequence<int, s1 - s0>{}, [&](auto D) { b_sub(RS{}, std::integral_constant<int, s0 + decltype(D)::value>{}, cur ^ 1); });
+                    // the NEXT chunk's patch: its sub-steps ride in the second half of the slots of taps TA0 .. 8
+                    if constexpr (t >= TA0) {
+                        constexpr int a0 = (t - TA0) * SA_PER, a1 = ((t - TA0 + 1) * SA_PER < NSA) ? (t - TA0 + 1) * SA_PER : NSA;
+                        constexpr int na = a1 > a0 ? a1 - a0 : 0;
+                        constexpr int half = SB / 2;
+                        if constexpr (m >= half) {
+                            constexpr int q0 = a0 + (m - half) * na / (SB - half), q1 = a0 + (m - half + 1) * na / (SB - half);
+                            if (!Y3_ABL(2))
+                                y3_for_each_ic(std::make_integer_sequence<int, q1 - q0>{}, [&](auto D) { patch_sub(std::integral_constant<int, q0 + decltype(D)::value>{}, cr ^ 1); });
+                        }
+                    }
+                } else {
+                    constexpr int q = m - SB;
+                    if constexpr (q == 0) set_addr(G{}, std::integral_constant<int, tn>{});
+                    if constexpr (q < RS2) {
+                        y3_for_each_ic(std::make_integer_sequence<int, 2>{}, [&](auto D) {
+                            constexpr int r = q * 2 + decltype(D)::value;
+                            if constexpr (r < MB)
+                                read_a(G{}, C0{}, r, crn);
+                            else if constexpr (r < MB + NB)
+                                read_b(G{}, C0{}, r - MB, cur ^ 1);
+                            else if constexpr (r < NR2)
+                                read_b(G{}, C1{}, r - MB - NB, cur ^ 1);
+                        });
+                    } else if constexpr (q < RS2 + B_LOADS) {
+                        if (!Y3_ABL(1)) b_load_one(RS{}, std::integral_constant<int, q - RS2>{}, srel + 4, std::integral_constant<int, (u + 4) % NT>{});
+                    } else if constexpr (t == 0 && q < RS2 + B_LOADS + (A4 + 1) / 2) {
+                        if (!Y3_ABL(1))
+                            y3_for_each_ic(std::make_integer_sequence<int, 2>{}, [&](auto D) {
+                                constexpr int jj = (q - RS2 - B_LOADS) * 2 + decltype(D)::value;
+                                if constexpr (jj < A4) patch_load_one(std::integral_constant<int, jj>{}, cp + cr + 1);
+                            });
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        // prologue: zero rows, the first chunk's patch and the first weight tile
+        if (tid < 12) {       // the all-zero row of both patch buffers, every piece and k half: 16 bytes each
+            const int pbuf = tid / 6, pl = tid % 6;
+            *reinterpret_cast<uint4*>(&lds[pbuf * AP + pl * AHP + PR * 8]) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        patch_load(0);
+        y3_for_each_ic(std::make_integer_sequence<int, B_LOADS>{}, [&](auto E) { b_load_one(C0{}, E, 0, C0{}); });
+        y3_for_each_ic(std::make_integer_sequence<int, NSA>{}, [&](auto E) { patch_sub(E, 0); });
+        y3_for_each_ic(std::make_integer_sequence<int, NSB>{}, [&](auto E) { b_sub(C0{}, E, 0); });
+        __syncthreads();
+        Y3_TSTAMP(1);
+        __builtin_amdgcn_sched_barrier(0);       // (pinned order: the set the loop consumes first must be the older one, see conv_x3_body)
+        y3_for_each_ic(std::make_integer_sequence<int, B_LOADS>{}, [&](auto E) { b_load_one(C1{}, E, 1, C1{}); });
+        __builtin_amdgcn_sched_barrier(0);
+        y3_for_each_ic(std::make_integer_sequence<int, B_LOADS>{}, [&](auto E) { b_load_one(C2{}, E, 2, C2{}); });
+        __builtin_amdgcn_sched_barrier(0);
+        y3_for_each_ic(std::make_integer_sequence<int, B_LOADS>{}, [&](auto E) { b_load_one(C0{}, E, 3, std::integral_constant<int, 3>{}); });
+        __builtin_amdgcn_sched_barrier(0);
+        set_addr(C0{}, C0{});
+#pragma unroll
+        for (int i = 0; i < MB; ++i) read_a(C0{}, C0{}, i, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            read_b(C0{}, C0{}, j, 0);
+            read_b(C0{}, C1{}, j, 0);
+        }
+        for (int cp = 0; cp < nchunks; cp += 2)
+            y3_for_each_ic(std::make_integer_sequence<int, 2 * NT>{}, [&](auto U) { step(U, cp); });
+    }
+    Y3_TSTAMP(2);
+    conv_fast_finish<BM, BN, WM, WN, true, BNS, true>(p, fw, acc, red);
+}
+
+template <int BM, int BN, int WM, int WN, bool BNS>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3p_kernel(const FastArgs p) {
+    conv_x3p_body<BM, BN, WM, WN, BNS>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // registers: two waves per SIMD (64 accumulators + 56 fragment + 32 staging registers per lane)
@@ -338,7 +652,31 @@ static void x3_launch_tile(const FastArgs& p, bool dense, int grid, hipStream_t 
 // Tiles this file is built for (conv.hip plans with them): false if (bm, bn) is not one of them.
 bool y3_x3_tile_ok(int bm, int bn) { return bm == 128 && (bn == 128 || bn == 64); }
 
+// The patch kernel takes a launch when: 3x3 stride 1 with the standard tap grid (dense destination), the patch fits the LDS rows
+// (BM + 2 (W + 1) <= Y3_X3P_ROWS), and every K slice is a whole, even number of 16-channel chunks (18 K steps).
+bool y3_x3p_ok(const FastArgs& p, int bm, int bn, bool dense) {
+    if (!(bm == 128 && bn == 128) || !dense || p.ntaps != 9 || p.sh != 1 || p.sw != 1) return false;
+    for (int t = 0; t < 9; ++t)
+        if (p.tap_dh[t] < -1 || p.tap_dh[t] > 1 || p.tap_dw[t] < -1 || p.tap_dw[t] > 1) return false;
+    if (bm + 2 * (p.W + 1) > Y3_X3P_ROWS) return false;
+    bool biased = false;                                                // src biased by exactly -(W + 1) pixels: tap (-1, -1) at offset 0
+    for (int t = 0; t < 9; ++t) biased |= p.tap_dh[t] == -1 && p.tap_dw[t] == -1 && p.tap_off[t] == 0;
+    if (!biased) return false;
+    if ((p.Cper % 32) != 0 || (p.K / 16) % 18 != 0) return false;
+    if ((p.sk_s0 > 1 && p.sk_chunk0 % 18 != 0) || (p.sk_s1 > 1 && p.sk_chunk1 % 18 != 0)) return false;
+    return true;
+}
+
 bool y3_x3_launch(const FastArgs& p, int bm, int bn, bool dense, int grid, hipStream_t st) {
+    static const int no_patch = getenv("Y3_X3_NO_PATCH") ? atoi(getenv("Y3_X3_NO_PATCH")) : 0;      // development: the im2col-order kernel for every launch
+    if (!no_patch && y3_x3p_ok(p, bm, bn, dense)) {
+        const dim3 g(grid), b(256);
+        if (p.bn_a)
+            hipLaunchKernelGGL((conv_x3p_kernel<128, 128, 2, 2, true>), g, b, 0, st, p);
+        else
+            hipLaunchKernelGGL((conv_x3p_kernel<128, 128, 2, 2, false>), g, b, 0, st, p);
+        return true;
+    }
     if (bm == 128 && bn == 128)
         x3_launch_tile<128, 128, 2, 2>(p, dense, grid, st);
     else if (bm == 128 && bn == 64)

@@ -19,7 +19,7 @@ import torch
 
 from . import _hip
 from . import streams
-from ._hip import lib, check, view, EPI_LRELU, EPI_ACCUM
+from ._hip import lib, check, view, EPI_LRELU, EPI_ACCUM, CONV_X3
 
 BN_EPS = 1e-3          # Keras BatchNormalization defaults
 BN_MOMENTUM = 0.99
@@ -233,6 +233,7 @@ class _Plan:
         act = torch.bfloat16 if bf else torch.float32      # activation storage type after the first layer
         self.in_nchw = torch.zeros(N, C, H, W, dtype=torch.float32, device=dev)
         self.ops = []      # high-level records for the backward emission
+        self.x3_fwd, self.x3_dgrad = [], []     # layers whose forward / data gradient runs the x3 kernels (bench.py: work per arithmetic)
         self.layer_out = []  # output activation of every conv_layer, creation order (debug / tests)
         li = [0]
 
@@ -276,12 +277,19 @@ class _Plan:
             scale, shift, smean, srstd, coef = ch, ch + cs, ch + 2 * cs, ch + 3 * cs, ch + 4 * cs
             mmean = mdl.moving.data_ptr() + 4 * sp.mv_off
             mvar = mdl.moving.data_ptr() + 4 * (mdl.moving_stride + sp.mv_off)
+            # fp32 arithmetic as three bf16 pieces per operand (conv_x3.hip) for the layers the model's policy names: the kernel then
+            # wants the copy of the weights with K contiguous per output column, i.e. the TRANSPOSED arena in the forward pass
+            x3 = CONV_X3 if (not bf and mdl.x3_forward(sp, N * oh * ow)) else 0
+            wfwd = (mdl.params_t.data_ptr() + 4 * sp.w_off) if x3 else ptr(sp.w_off)
+            fneed = int(lib.y3_conv2d_fwd_workspace_x(N * oh * ow, sp.cin_pad, sp.k, sp.cout, x3))
+            if x3:
+                self.x3_fwd.append(i)
             if tr:
                 a = self._new(N, oh, ow, sp.cout)
-                tiles = lib.y3_conv2d_stats_tiles(a.m, sp.cin_pad, sp.k, sp.cout)
+                tiles = lib.y3_conv2d_stats_tiles_x(a.m, sp.cin_pad, sp.k, sp.cout, x3)
                 assert tiles * 2 * sp.cout <= self.stats_ws.numel()
-                self._conv_call(self.fwd, a.m, sp, lib.y3_conv2d_fwd, src.v, ptr(sp.w_off), ptr(sp.b_off), sp.k, sp.s, a.v, EPI_LRELU,
-                                LRELU_ALPHA, None, None, None, self.stats_ws.data_ptr())
+                self._conv_call(self.fwd, a.m, sp, lib.y3_conv2d_fwd, src.v, wfwd, ptr(sp.b_off), sp.k, sp.s, a.v, EPI_LRELU | x3,
+                                LRELU_ALPHA, None, None, None, self.stats_ws.data_ptr(), need=fneed)
                 self._emit(self.fwd, lib.y3_bn_stats_finalize, self.stats_ws.data_ptr(), tiles, sp.cout, a.m, ptr(sp.g_off), ptr(sp.be_off),
                            BN_EPS, BN_MOMENTUM, mmean, mvar, smean, srstd, scale, shift)
                 self._emit(self.fwd, lib.y3_bn_apply, a.v, scale, shift, resid.v if resid is not None else None, y.v)
@@ -301,8 +309,8 @@ class _Plan:
                                 LRELU_ALPHA, scale, shift, None, None)
                 self._emit(self.fwd, lib.y3_f32_to_bf16, y32.buf.data_ptr(), y.buf.data_ptr(), y.buf.numel())
             else:
-                self._conv_call(self.fwd, y.m, sp, lib.y3_conv2d_fwd, src.v, ptr(sp.w_off), ptr(sp.b_off), sp.k, sp.s, y.v, EPI_LRELU,
-                                LRELU_ALPHA, scale, shift, resid.v if resid is not None else None, None)
+                self._conv_call(self.fwd, y.m, sp, lib.y3_conv2d_fwd, src.v, wfwd, ptr(sp.b_off), sp.k, sp.s, y.v, EPI_LRELU | x3,
+                                LRELU_ALPHA, scale, shift, resid.v if resid is not None else None, None, need=fneed)
             self.layer_out.append(y)
             return y
 
@@ -460,7 +468,7 @@ class _Plan:
                 csp = specs[cons[1]]
                 ca = cons[3]
                 dd = view(self.dz, ca.n, ca.h, ca.w, csp.cout)
-                tiles = int(lib.y3_conv2d_dgrad_bn_tiles(dd, csp.k, csp.s, y.v))
+                tiles = int(lib.y3_conv2d_dgrad_bn_tiles_x(dd, csp.k, csp.s, y.v, CONV_X3 if mdl.x3_dgrad(csp, y.m) else 0))
                 if tiles <= 0:
                     continue
                 part = torch.empty(tiles * 6 * y.c, dtype=torch.float32, device=mdl.device)
@@ -553,15 +561,19 @@ class _Plan:
                     self._emit(self.bwd, lib.y3_conv2d_wgrad, src.v, dz.v, sp.k, sp.s, gptr(sp.w_off), self.wg_ws.data_ptr(), self.wg_ws_bytes)
                 if src is not first_src:
                     ds = self._grad_of(src)
+                    # x3 data gradient: the kernel wants K (= this layer's output channels) contiguous per column: the Keras arena
+                    x3 = CONV_X3 if mdl.x3_dgrad(sp, ds.m) else 0
+                    wdg = (mdl.params.data_ptr() if x3 else Wt.data_ptr()) + 4 * sp.w_off
+                    dflags = (EPI_ACCUM if src.gw else 0) | x3
+                    dneed = int(lib.y3_conv2d_dgrad_workspace_x(dz.v, sp.k, sp.s, ds.v, x3))
+                    if x3:
+                        self.x3_dgrad.append(i)
                     if id(op) in epi_of:      # this launch completes d(src): it also sums the BatchNorm-backward moments of the producer
                         pa, part, _ = epi_of[id(op)]
-                        self._conv_call(self.bwd, ds.m, sp, lib.y3_conv2d_dgrad_bn, dz.v, Wt.data_ptr() + 4 * sp.w_off, sp.k, sp.s, ds.v,
-                                        EPI_ACCUM if src.gw else 0, pa.v, part.data_ptr(),
-                                        need=int(lib.y3_conv2d_dgrad_workspace(dz.v, sp.k, sp.s, ds.v)))
+                        self._conv_call(self.bwd, ds.m, sp, lib.y3_conv2d_dgrad_bn, dz.v, wdg, sp.k, sp.s, ds.v, dflags, pa.v, part.data_ptr(), need=dneed)
                         self.keep.append(part)
                     else:
-                        self._conv_call(self.bwd, ds.m, sp, lib.y3_conv2d_dgrad, dz.v, Wt.data_ptr() + 4 * sp.w_off, sp.k, sp.s, ds.v,
-                                        EPI_ACCUM if src.gw else 0, need=int(lib.y3_conv2d_dgrad_workspace(dz.v, sp.k, sp.s, ds.v)))
+                        self._conv_call(self.bwd, ds.m, sp, lib.y3_conv2d_dgrad, dz.v, wdg, sp.k, sp.s, ds.v, dflags, need=dneed)
                     src.mark_written()
                 self.bwd.append(('layer_done', i))
         for e in dz_busy + head_wg[-1:]:
@@ -651,7 +663,7 @@ class YoloV3:
     WEIGHT_DECAY = 5e-4      # declared by the reference but never applied (Q9)
 
     def __init__(self, global_batch_size, img_size, number_classes, anchors=None, learning_rate=1e-4, device=None, seed=None,
-                 use_graph=False, inference_precision='fp32'):
+                 use_graph=False, inference_precision='fp32', conv_arithmetic=None):
         if not torch.cuda.is_available():
             raise RuntimeError('yolo3.model.YoloV3 needs an MI355X (HIP) device: there is no CPU path')
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
@@ -691,6 +703,14 @@ class YoloV3:
         if inference_precision not in ('fp32', 'bf16'):
             raise ValueError("inference_precision must be 'fp32' or 'bf16'")
         self.inference_precision = inference_precision   # predict() default; training is always fp32
+        # fp32 convolutions: 'f32' = v_mfma_f32_32x32x2_f32 everywhere; 'x3' = the layers named by x3_forward / x3_dgrad run their
+        # fp32 arithmetic as three bf16 pieces per operand on the bf16 matrix pipe (Y3_CONV_X3, conv_x3.hip: fp32-class results,
+        # 2.67x fewer matrix-pipe cycles).  Default 'x3'; environment Y3_CONV_X3=0 / 1 / all overrides the default.
+        if conv_arithmetic is None:
+            conv_arithmetic = {'0': 'f32', '1': 'x3', 'all': 'x3-all'}.get(os.environ.get('Y3_CONV_X3', '1'), 'x3')
+        if conv_arithmetic not in ('f32', 'x3', 'x3-all'):
+            raise ValueError("conv_arithmetic must be 'f32' or 'x3'")
+        self.conv_arithmetic = conv_arithmetic
         self.params_t_bf16 = None                 # bf16 copy of params_t, made on first bf16 predict
         self._bf16_stale = True
         self.dist = None                          # set by parallel.DataParallel.attach()
@@ -701,6 +721,21 @@ class YoloV3:
         self.model = _CallableModel(self, False)
         self.model_feature_maps = _CallableModel(self, True)
         self.optimizer = self
+
+    # ---- which launches run the x3 kernels ---------------------------------------
+    def _x3_policy(self, c, ntaps, nout, m, stride):
+        if self.conv_arithmetic == 'f32' or stride != 1 or not lib.y3_conv2d_x3_ok(m, c, ntaps, nout):
+            return False
+        if self.conv_arithmetic == 'x3-all':
+            return True
+        # measured (tools/x3_check.py, batch 8 at 416^2): the 3x3 layers with >= 128 contracted channels per tap gain 1.3-1.5x
+        return ntaps == 9 and c >= 128 and nout >= 128
+
+    def x3_forward(self, sp, m_out):
+        return self._x3_policy(sp.cin_pad, sp.k * sp.k, sp.cout, m_out, sp.s)
+
+    def x3_dgrad(self, sp, m_in):
+        return self._x3_policy(sp.cout, sp.k * sp.k, sp.cin_pad, m_in, sp.s)
 
     # ---- construction helpers --------------------------------------------------
     def _init_weights(self, seed):

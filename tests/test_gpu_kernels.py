@@ -49,11 +49,23 @@ CONV_CASES = [
 ]
 
 
+def _x3_or_skip(hip, arith, m, c, taps, nout):
+    """flags for the arithmetic under test; skips the x3 variant of shapes the x3 kernels do not take (y3_conv2d_x3_ok)"""
+    if arith == 'f32':
+        return 0
+    if not hip.lib.y3_conv2d_x3_ok(m, c, taps, nout):
+        pytest.skip('Y3_CONV_X3 does not take this shape')
+    return hip.CONV_X3
+
+
+@pytest.mark.parametrize('arith', ['f32', 'x3'])
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv_fwd(hip, case):
-    """y3_conv2d_fwd vs fp64 conv2d; tolerance 2e-5 * max|ref| (fp32 fmaf chain over K <= 1152)."""
+def test_conv_fwd(hip, case, arith):
+    """y3_conv2d_fwd vs fp64 conv2d; tolerance 2e-5 * max|ref| (fp32 fmaf chain over K <= 1152).  arith = 'x3': the same
+    call with Y3_CONV_X3 (three bf16 pieces per operand, weights in the transposed layout), same tolerance."""
     from util import nhwc_buf, stream, assert_close
     n, h, w, cin, cout, k, s = case
+    x3 = _x3_or_skip(hip, arith, n * (-(-h // s)) * (-(-w // s)), cin, k * k, cout)
     g = torch.Generator().manual_seed(hash(case) % 1000)
     x = torch.randn(n, cin, h, w, generator=g)
     if cin == 4:
@@ -65,14 +77,14 @@ def test_conv_fwd(hip, case):
     sv.copy_(x.permute(0, 2, 3, 1))
     old = (cout + 3) // 4 * 4 + 4
     dbuf, dv = nhwc_buf(n, oh, ow, cout, ld=old)
-    wd, bd = wk.contiguous().cuda(), b.cuda()
+    wd, bd = (wk.permute(0, 1, 3, 2) if x3 else wk).contiguous().cuda(), b.cuda()      # x3: [kh,kw,co,ci]
     src = hip.Tensor(sv.data_ptr(), n, h, w, cin, cin + 8)
     dst = hip.Tensor(dv.data_ptr(), n, oh, ow, cout, old)
-    tiles = hip.lib.y3_conv2d_stats_tiles(n * oh * ow, cin, k, cout)
+    tiles = hip.lib.y3_conv2d_stats_tiles_x(n * oh * ow, cin, k, cout, x3)
     stats = torch.full((tiles * 2 * cout,), float('nan'), device='cuda')
-    wsb = int(hip.lib.y3_conv2d_fwd_workspace(n * oh * ow, cin, k, cout))
+    wsb = int(hip.lib.y3_conv2d_fwd_workspace_x(n * oh * ow, cin, k, cout, x3))
     ws = torch.zeros(wsb // 4 + 4, device='cuda')        # tickets in the head: zeroed once (yolo3hip.h)
-    hip.check(hip.lib.y3_conv2d_fwd(src, wd.data_ptr(), bd.data_ptr(), k, s, dst, hip.EPI_LRELU, 0.2, None, None, None, stats.data_ptr(),
+    hip.check(hip.lib.y3_conv2d_fwd(src, wd.data_ptr(), bd.data_ptr(), k, s, dst, hip.EPI_LRELU | x3, 0.2, None, None, None, stats.data_ptr(),
                                     ws.data_ptr(), wsb, stream()))
     ref = F.leaky_relu(_conv_ref(x, wk, b, k, s), 0.2)
     assert_close(dv.cpu().permute(0, 3, 1, 2), ref, rtol=2e-5, what='conv fwd')
@@ -84,11 +96,13 @@ def test_conv_fwd(hip, case):
         assert torch.isnan(dbuf.view(-1, old)[:, cout:]).all()
 
 
+@pytest.mark.parametrize('arith', ['f32', 'x3'])
 @pytest.mark.parametrize('shape', [(2, 26, 26, 64, 128, 3, 1), (1, 13, 13, 512, 1024, 3, 1), (1, 13, 13, 1024, 512, 1, 1), (1, 26, 26, 1024, 256, 1, 1)])
-def test_conv_fwd_fused_inference_epilogue(hip, shape):
+def test_conv_fwd_fused_inference_epilogue(hip, shape, arith):
     """lrelu -> scale/shift -> + resid (inference-mode BN folded, model.py:38,47); the small-M shapes take the split-K path."""
     from util import nhwc_buf, stream, assert_close
     n, h, w, cin, cout, k, s = shape
+    x3 = _x3_or_skip(hip, arith, n * h * w, cin, k * k, cout)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(n, cin, h, w, generator=g)
     wk = torch.randn(k, k, cin, cout, generator=g) * 0.05
@@ -101,11 +115,11 @@ def test_conv_fwd_fused_inference_epilogue(hip, shape):
     _, rv = nhwc_buf(n, h, w, cout, ld=2 * cout, off=cout)
     rv.copy_(r.permute(0, 2, 3, 1))
     _, dv = nhwc_buf(n, h, w, cout)
-    wd, bd, scd, shd = wk.contiguous().cuda(), b.cuda(), sc.cuda(), sh.cuda()
-    wsb = int(hip.lib.y3_conv2d_fwd_workspace(n * h * w, cin, k, cout))
+    wd, bd, scd, shd = (wk.permute(0, 1, 3, 2) if x3 else wk).contiguous().cuda(), b.cuda(), sc.cuda(), sh.cuda()
+    wsb = int(hip.lib.y3_conv2d_fwd_workspace_x(n * h * w, cin, k, cout, x3))
     ws = torch.zeros(wsb // 4 + 4, device='cuda')        # tickets in the head: zeroed once (yolo3hip.h)
     hip.check(hip.lib.y3_conv2d_fwd(hip.Tensor(sv.data_ptr(), n, h, w, cin, cin), wd.data_ptr(), bd.data_ptr(), k, s,
-                                    hip.Tensor(dv.data_ptr(), n, h, w, cout, cout), hip.EPI_LRELU, 0.2, scd.data_ptr(), shd.data_ptr(),
+                                    hip.Tensor(dv.data_ptr(), n, h, w, cout, cout), hip.EPI_LRELU | x3, 0.2, scd.data_ptr(), shd.data_ptr(),
                                     hip.Tensor(rv.data_ptr(), n, h, w, cout, 2 * cout), None, ws.data_ptr(), wsb, stream()))
     ref = F.leaky_relu(_conv_ref(x, wk, b, k, s), 0.2) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None] + r.double()
     assert_close(dv.cpu().permute(0, 3, 1, 2), ref, rtol=2e-5, what='fused epilogue')
@@ -321,12 +335,16 @@ DGRAD_CASES = [
 ]
 
 
+@pytest.mark.parametrize('arith', ['f32', 'x3'])
 @pytest.mark.parametrize('case', DGRAD_CASES)
 @pytest.mark.parametrize('accum', [False, True])
-def test_conv_dgrad(hip, case, accum):
-    """y3_conv2d_dgrad vs autograd of the fp64 conv; 2e-5 * max|ref|."""
+def test_conv_dgrad(hip, case, accum, arith):
+    """y3_conv2d_dgrad vs autograd of the fp64 conv; 2e-5 * max|ref|.  arith = 'x3': Y3_CONV_X3 (stride 1 only), weights in the Keras layout."""
     from util import nhwc_buf, stream, assert_close
     n, h, w, cin, cout, k, s = case
+    if arith == 'x3' and s != 1:
+        pytest.skip('Y3_CONV_X3 data gradients are built for stride 1')
+    x3 = _x3_or_skip(hip, arith, n * h * w, cout, k * k, cin)
     g = torch.Generator().manual_seed(11)
     x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64, requires_grad=True)
     wk = torch.randn(k, k, cin, cout, generator=g) * 0.1
@@ -348,9 +366,9 @@ def test_conv_dgrad(hip, case, accum):
     hip.check(hip.lib.y3_transpose_weights(wd.data_ptr(), wt2.data_ptr(), k * k, cin, cout, stream()))
     assert torch.equal(wt, wt2)
     DD, DS = hip.Tensor(ddv.data_ptr(), n, oh, ow, cout, cld), hip.Tensor(dsv.data_ptr(), n, h, w, cin, cin + 4)
-    wsb = int(hip.lib.y3_conv2d_dgrad_workspace(DD, k, s, DS))
+    wsb = int(hip.lib.y3_conv2d_dgrad_workspace_x(DD, k, s, DS, x3))
     ws = torch.zeros(wsb // 4 + 4, device='cuda')        # tickets in the head: zeroed once (yolo3hip.h)
-    hip.check(hip.lib.y3_conv2d_dgrad(DD, wt2.data_ptr(), k, s, DS, hip.EPI_ACCUM if accum else 0, ws.data_ptr(), wsb, stream()))
+    hip.check(hip.lib.y3_conv2d_dgrad(DD, (wd if x3 else wt2).data_ptr(), k, s, DS, (hip.EPI_ACCUM if accum else 0) | x3, ws.data_ptr(), wsb, stream()))
     ref = x.grad.permute(0, 2, 3, 1)
     if accum:
         ref = ref + init.double()
@@ -359,8 +377,9 @@ def test_conv_dgrad(hip, case, accum):
 
 @pytest.mark.parametrize('shape', [(8, 13, 13, 512, 1024, 3), (8, 26, 26, 128, 256, 1), (2, 52, 52, 64, 128, 3), (8, 52, 52, 128, 256, 3), (1, 13, 15, 64, 32, 1),
                                    (2, 104, 104, 64, 128, 3, 2), (8, 26, 26, 256, 512, 3, 2), (1, 30, 26, 32, 64, 3, 2)])
+@pytest.mark.parametrize('arith', ['f32', 'x3'])
 @pytest.mark.parametrize('accum', [False, True])
-def test_conv_dgrad_bn_epilogue_stats(hip, shape, accum):
+def test_conv_dgrad_bn_epilogue_stats(hip, shape, accum, arith):
     """y3_conv2d_dgrad_bn: the data gradient is bit-identical to y3_conv2d_dgrad's, and the per-row-tile partial moments
     it leaves behind, through y3_bn_bwd_finalize_tiles, give the dgamma / dbeta / dbias / coefficients that y3_bn_bwd_stats
     computes from the finished gradient (fp32 tile sums vs fp64 running sums: 2e-5 of the largest value per quantity;
@@ -371,6 +390,9 @@ def test_conv_dgrad_bn_epilogue_stats(hip, shape, accum):
     n, h, w, cin, cout, k = shape[:6]      # conv cin -> cout; its data gradient has cin channels (h, w: the conv's INPUT size)
     s_ = shape[6] if len(shape) > 6 else 1   # stride 2: the merged launch of the four parity classes carries the statistics
     oh, ow = -(-h // s_), -(-w // s_)
+    if arith == 'x3' and s_ != 1:
+        pytest.skip('Y3_CONV_X3 data gradients are built for stride 1')
+    x3 = _x3_or_skip(hip, arith, n * h * w, cout, k * k, cin)
     g = torch.Generator().manual_seed(cin * 3 + cout + k)
     dy = torch.randn(n, oh, ow, cout, generator=g)
     wk = torch.randn(k, k, cin, cout, generator=g) * 0.05
@@ -381,7 +403,7 @@ def test_conv_dgrad_bn_epilogue_stats(hip, shape, accum):
     ddv.copy_(dy)
     _, av = nhwc_buf(n, h, w, cin, ld=cin + 8)
     av.copy_(a)
-    wt = wk.permute(0, 1, 3, 2).contiguous().cuda()
+    wt = (wk if x3 else wk.permute(0, 1, 3, 2)).contiguous().cuda()      # x3: the Keras layout, K (= cout) contiguous per column
     DD, A = hip.Tensor(ddv.data_ptr(), n, oh, ow, cout, cout), hip.Tensor(av.data_ptr(), n, h, w, cin, cin + 8)
     outs = []
     for fused in (False, True):
@@ -389,11 +411,11 @@ def test_conv_dgrad_bn_epilogue_stats(hip, shape, accum):
         if accum:
             dsv.copy_(init)
         DS = hip.Tensor(dsv.data_ptr(), n, h, w, cin, cin + 4)
-        wsb = int(hip.lib.y3_conv2d_dgrad_workspace(DD, k, s_, DS))
+        wsb = int(hip.lib.y3_conv2d_dgrad_workspace_x(DD, k, s_, DS, x3))
         ws = torch.zeros(wsb // 4 + 4, device='cuda')
-        flags = hip.EPI_ACCUM if accum else 0
+        flags = (hip.EPI_ACCUM if accum else 0) | x3
         if fused:
-            tiles = int(hip.lib.y3_conv2d_dgrad_bn_tiles(DD, k, s_, DS))
+            tiles = int(hip.lib.y3_conv2d_dgrad_bn_tiles_x(DD, k, s_, DS, x3))
             assert tiles > 0
             part = torch.full((tiles * 6 * cin,), float('nan'), device='cuda')
             hip.check(hip.lib.y3_conv2d_dgrad_bn(DD, wt.data_ptr(), k, s_, DS, flags, A, part.data_ptr(), ws.data_ptr(), wsb, stream()))
@@ -429,6 +451,80 @@ def test_conv_dgrad_bn_epilogue_stats(hip, shape, accum):
     for acc in (0, 1):
         hip.check(hip.lib.y3_bn_bwd_apply_fanin(DSC, A, ref[3].data_ptr(), 0.2, hip.Tensor(dzf.data_ptr(), n, h, w, cin, cin), DR, acc, stream()))
     assert torch.equal(dzr, dzf) and torch.equal(drv.cpu(), 2 * outs[0].cpu())
+
+
+# the 23 distinct convolution shapes of the network at 416 x 416 (cin as the kernels see it: 3 -> 4), batch 1
+APP_A = [(416, 4, 32, 3, 1), (416, 32, 64, 3, 2), (208, 64, 32, 1, 1), (208, 32, 64, 3, 1), (208, 64, 128, 3, 2), (104, 128, 64, 1, 1),
+         (104, 64, 128, 3, 1), (104, 128, 256, 3, 2), (52, 256, 128, 1, 1), (52, 128, 256, 3, 1), (52, 256, 512, 3, 2), (26, 512, 256, 1, 1),
+         (26, 256, 512, 3, 1), (26, 512, 1024, 3, 2), (13, 1024, 512, 1, 1), (13, 512, 1024, 3, 1), (13, 512, 512, 1, 1), (26, 1024, 256, 1, 1),
+         (26, 256, 256, 1, 1), (52, 512, 128, 1, 1), (13, 1024, 14, 1, 1), (26, 512, 14, 1, 1), (52, 256, 14, 1, 1)]
+
+
+@pytest.mark.parametrize('shape', APP_A)
+def test_conv_x3_error_against_fp64_is_that_of_the_f32_instruction(hip, shape):
+    """The reporting rule for Y3_CONV_X3 (quoted in DESIGN.md): on every Appendix-A shape the x3 kernels take, forward
+    and stride-1 data gradient, the maximum error against fp64 is at most 2x that of the v_mfma_f32 kernel ON THE SAME INPUTS
+    (measured: 0.5-0.9x -- the pieces are exact and the 32x32x16 instruction rounds once per 16 products).  Shapes x3 does not
+    take (the RGB layer, the 14-channel heads, stride-2 data gradients) must be refused loudly, not computed some other way."""
+    from util import nhwc_buf, stream
+    hw, cin, cout, k, s = shape
+    n = 1 if hw >= 104 else 2
+    oh = -(-hw // s)
+    g = torch.Generator().manual_seed(hw * 7 + cin + cout + k)
+    x = torch.randn(n, cin, hw, hw, generator=g)
+    wk = torch.randn(k, k, cin, cout, generator=g) * (1.0 / (k * k * cin) ** 0.5)
+    dy = torch.randn(n, cout, oh, oh, generator=g)
+    _, xv = nhwc_buf(n, hw, hw, cin)
+    xv.copy_(x.permute(0, 2, 3, 1))
+    cld = (cout + 3) // 4 * 4              # pixel pitch: a multiple of 4 floats (the 14-channel heads)
+    _, dyv = nhwc_buf(n, oh, oh, cout, ld=cld)
+    dyv.copy_(dy.permute(0, 2, 3, 1))
+    w_keras, w_t = wk.contiguous().cuda(), wk.permute(0, 1, 3, 2).contiguous().cuda()
+    X, DY = hip.Tensor(xv.data_ptr(), n, hw, hw, cin, cin), hip.Tensor(dyv.data_ptr(), n, oh, oh, cout, cld)
+    m = n * oh * oh
+    ok = bool(hip.lib.y3_conv2d_x3_ok(m, cin, k * k, cout))
+    assert ok == (cin % 16 == 0 and cout >= 32)
+    # forward
+    xr = x.double().requires_grad_(True)
+    ref = _conv_ref(xr, wk, None, k, s)
+    outs = {}
+    for name, flag, wt in (('f32', 0, w_keras), ('x3', hip.CONV_X3, w_t)):
+        _, yv = nhwc_buf(n, oh, oh, cout, ld=cld)
+        wsb = int(hip.lib.y3_conv2d_fwd_workspace_x(m, cin, k, cout, flag))
+        ws = torch.zeros(wsb // 4 + 4, device='cuda')
+        rc = hip.lib.y3_conv2d_fwd(X, wt.data_ptr(), None, k, s, hip.Tensor(yv.data_ptr(), n, oh, oh, cout, cld), flag, 0.0, None, None, None, None,
+                                   ws.data_ptr(), wsb, stream())
+        if flag and not ok:
+            assert rc != 0, 'x3 accepted a shape y3_conv2d_x3_ok() refuses'
+            continue
+        hip.check(rc, 'conv fwd ' + name)
+        outs[name] = float((yv.cpu().permute(0, 3, 1, 2).double() - ref.detach()).abs().max())
+    scale = float(ref.detach().abs().max())
+    assert outs['f32'] <= 2e-5 * scale
+    if ok:
+        assert outs['x3'] <= max(2.0 * outs['f32'], 2e-7 * scale), 'forward: x3 error %.3e vs f32 %.3e' % (outs['x3'], outs['f32'])
+    # data gradient (not for the RGB layer: the network never asks for it)
+    if cin == 4:
+        return
+    ref.backward(dy.double())
+    refd = xr.grad.permute(0, 2, 3, 1)
+    okd = bool(hip.lib.y3_conv2d_x3_ok(n * hw * hw, cout, k * k, cin)) and s == 1
+    outs = {}
+    for name, flag, wt in (('f32', 0, w_t), ('x3', hip.CONV_X3, w_keras)):
+        _, dxv = nhwc_buf(n, hw, hw, cin, fill=0.0)
+        DX = hip.Tensor(dxv.data_ptr(), n, hw, hw, cin, cin)
+        wsb = int(hip.lib.y3_conv2d_dgrad_workspace_x(DY, k, s, DX, flag))
+        ws = torch.zeros(wsb // 4 + 4, device='cuda')
+        rc = hip.lib.y3_conv2d_dgrad(DY, wt.data_ptr(), k, s, DX, flag, ws.data_ptr(), wsb, stream())
+        if flag and not okd:
+            assert rc != 0, 'x3 data gradient accepted a shape it is not built for'
+            continue
+        hip.check(rc, 'conv dgrad ' + name)
+        outs[name] = float((dxv.cpu().double() - refd).abs().max())
+    scale = float(refd.abs().max())
+    assert outs['f32'] <= 2e-5 * scale
+    if okd:
+        assert outs['x3'] <= max(2.0 * outs['f32'], 2e-7 * scale), 'data gradient: x3 error %.3e vs f32 %.3e' % (outs['x3'], outs['f32'])
 
 
 WGRAD_CASES = CONV_CASES[:6] + CONV_CASES[9:10] + [(8, 52, 52, 128, 256, 1, 1), (2, 64, 64, 32, 64, 3, 2)]

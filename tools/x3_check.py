@@ -17,6 +17,7 @@ ap.add_argument('--no-ref', action='store_true')
 ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--x3-only', action='store_true')
+ap.add_argument('--pad', type=int, default=0, help='pixel pitch of the activations = channels + pad floats')
 ap.add_argument('--all', action='store_true', help='every stride-1 shape of the net the x3 kernels take')
 args = ap.parse_args()
 N = args.batch
@@ -60,26 +61,29 @@ for (n, h, w, cin, cout, k) in SHAPES:
     x = torch.randn(n, cin, h, w, generator=g)
     wk = torch.randn(k, k, cin, cout, generator=g) * (1.0 / (taps * cin) ** 0.5)
     dy = torch.randn(n, cout, h, w, generator=g)
-    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
-    dyd = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    PAD = args.pad
+    xd = torch.zeros(n, h, w, cin + PAD, device='cuda')
+    xd[..., :cin] = x.permute(0, 2, 3, 1).cuda()
+    dyd = torch.zeros(n, h, w, cout + PAD, device='cuda')
+    dyd[..., :cout] = dy.permute(0, 2, 3, 1).cuda()
     wd = wk.contiguous().cuda()                                   # [tap][cin][cout]
     wtd = wk.permute(0, 1, 3, 2).contiguous().cuda()              # [tap][cout][cin]
     b = torch.zeros(cout, device='cuda')
-    yo = [torch.empty(n, h, w, cout, device='cuda') for _ in range(2)]
-    dxo = [torch.empty(n, h, w, cin, device='cuda') for _ in range(2)]
-    X = _hip.Tensor(xd.data_ptr(), n, h, w, cin, cin)
-    DY = _hip.Tensor(dyd.data_ptr(), n, h, w, cout, cout)
+    yo = [torch.empty(n, h, w, cout + PAD, device='cuda') for _ in range(2)]
+    dxo = [torch.empty(n, h, w, cin + PAD, device='cuda') for _ in range(2)]
+    X = _hip.Tensor(xd.data_ptr(), n, h, w, cin, cin + PAD)
+    DY = _hip.Tensor(dyd.data_ptr(), n, h, w, cout, cout + PAD)
     m = n * h * w
     ws = torch.zeros(max(int(lib.y3_conv2d_fwd_workspace_x(m, cin, k, cout, f)) for f in (0, _hip.CONV_X3)) // 4 + (64 << 20) // 4, device='cuda')
     wsb = ws.numel() * 4
 
     def fwd(x3):
-        Y = _hip.Tensor(yo[x3].data_ptr(), n, h, w, cout, cout)
+        Y = _hip.Tensor(yo[x3].data_ptr(), n, h, w, cout, cout + PAD)
         _hip.check(lib.y3_conv2d_fwd(X, (wtd if x3 else wd).data_ptr(), b.data_ptr(), k, 1, Y, _hip.EPI_LRELU | (_hip.CONV_X3 if x3 else 0), 0.2,
                                      None, None, None, None, ws.data_ptr(), wsb, st), 'fwd')
 
     def dgrad(x3):
-        DX = _hip.Tensor(dxo[x3].data_ptr(), n, h, w, cin, cin)
+        DX = _hip.Tensor(dxo[x3].data_ptr(), n, h, w, cin, cin + PAD)
         _hip.check(lib.y3_conv2d_dgrad(DY, (wd if x3 else wtd).data_ptr(), k, 1, DX, _hip.CONV_X3 if x3 else 0, ws.data_ptr(), wsb, st), 'dgrad')
 
     ok_f = lib.y3_conv2d_x3_ok(m, cin, taps, cout)
@@ -102,13 +106,13 @@ for (n, h, w, cin, cout, k) in SHAPES:
         for nm, t_ in (('f32', yo[0]), ('x3', yo[1])):
             if nm == 'x3' and not ok_f:
                 continue
-            err = (t_[:nr].cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+            err = (t_[:nr, ..., :cout].cpu().double() - ref).abs().max().item() / ref.abs().max().item()
             line += ' fwd %s err %.2e' % (nm, err)
         wflip = wk.double().flip(0, 1).permute(2, 3, 0, 1)          # conv_transpose as a conv with the flipped kernel: [cin][cout][kh][kw]
         refd = F.conv2d(dy[:nr].double(), wflip, padding=k // 2).permute(0, 2, 3, 1)
         for nm, t_ in (('f32', dxo[0]), ('x3', dxo[1])):
             if nm == 'x3' and not ok_d:
                 continue
-            err = (t_[:nr].cpu().double() - refd).abs().max().item() / refd.abs().max().item()
+            err = (t_[:nr, ..., :cin].cpu().double() - refd).abs().max().item() / refd.abs().max().item()
             line += ' dgrad %s err %.2e' % (nm, err)
     print(line, flush=True)
