@@ -1045,7 +1045,11 @@ static ConvPlan plan_conv_x3(int M, int Nout, int K, int ntaps) {
     pl.tiles = pl.f = tiles;
     pl.s0 = pl.s1 = 1;
     pl.chunk0 = pl.chunk1 = even_steps(nk);
-    static const int want = env_int("Y3_X3_WGS", 700);
+    // measured (tools/probe/x3_sweep5.sh, batch 8 at 416^2): two workgroups of the patch kernel share a CU (75 KB of LDS each), so a
+    // launch wants at most 512 pieces; ~350 (1.4 per CU) beat ~700 (a second, mostly idle round) on every 3x3 shape but the
+    // data gradients with fewer than 64 tiles, whose slices are 72+ steps long either way
+    static const int want_env = env_int("Y3_X3_WGS", 0);
+    const int want = want_env > 0 ? want_env : (y3_cdiv(M, 128) * y3_cdiv(Nout, Nout <= 64 ? 64 : 128) < 64 ? 700 : 350);
     static const int min_steps = env_int("Y3_X3_MINSTEPS", 12);
     // slices are whole units of K steps: 3x3 launches in units of 18 (two 16-channel chunks of nine taps: the patch kernel's loop
     // body, conv_x3.hip), the others in pairs of steps
@@ -1055,6 +1059,10 @@ static ConvPlan plan_conv_x3(int M, int Nout, int K, int ntaps) {
         int ks = (want + tiles / 2) / tiles;
         if (ks > nk / min_steps) ks = nk / min_steps;
         if (ks > 16) ks = 16;
+        {
+            static const int force_ks = env_int("Y3_X3_KS", 0);      // development: this many K slices for every split launch
+            if (force_ks > 0) ks = force_ks;
+        }
         if (ks > 1) {
             pl.chunk0 = y3_cdiv(y3_cdiv(nk, ks), unit) * unit;
             pl.s0 = y3_cdiv(nk, pl.chunk0);

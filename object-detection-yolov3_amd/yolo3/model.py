@@ -723,19 +723,25 @@ class YoloV3:
         self.optimizer = self
 
     # ---- which launches run the x3 kernels ---------------------------------------
-    def _x3_policy(self, c, ntaps, nout, m, stride):
-        if self.conv_arithmetic == 'f32' or stride != 1 or not lib.y3_conv2d_x3_ok(m, c, ntaps, nout):
+    def _x3_policy(self, c, ntaps, nout, m, stride, forward):
+        if self.conv_arithmetic == 'f32' or not lib.y3_conv2d_x3_ok(m, c, ntaps, nout) or (stride != 1 and not forward):
             return False
         if self.conv_arithmetic == 'x3-all':
             return True
-        # measured (tools/x3_check.py, batch 8 at 416^2): the 3x3 layers with >= 128 contracted channels per tap gain 1.3-1.5x
-        return ntaps == 9 and c >= 128 and nout >= 128
+        # measured (tools/x3_check.py, batch 8 at 416^2, launch by launch and inside the step): the 3x3 layers gain -- forward
+        # 1.2-1.7x from 64 input channels up and on every stride-2 layer, stride-1 data gradients 1.3-1.5x with >= 128 contracted
+        # channels; the 1x1 layers (4-64 K steps: prologue + epilogue bound) and the 32-channel layers do not
+        if ntaps != 9:
+            return False
+        if forward:
+            return c >= 64 or stride == 2
+        return c >= 128 and nout >= 128
 
     def x3_forward(self, sp, m_out):
-        return self._x3_policy(sp.cin_pad, sp.k * sp.k, sp.cout, m_out, sp.s)
+        return self._x3_policy(sp.cin_pad, sp.k * sp.k, sp.cout, m_out, sp.s, True)
 
     def x3_dgrad(self, sp, m_in):
-        return self._x3_policy(sp.cout, sp.k * sp.k, sp.cin_pad, m_in, sp.s)
+        return self._x3_policy(sp.cout, sp.k * sp.k, sp.cin_pad, m_in, sp.s, False)
 
     # ---- construction helpers --------------------------------------------------
     def _init_weights(self, seed):

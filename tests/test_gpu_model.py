@@ -21,6 +21,11 @@ pytestmark = pytest.mark.gpu
 # excess 6.7e-4.  The floor is ~2.4 x the largest excess.  The per-kernel tests (2e-5 .. 1e-4 against fp64) carry the real weight:
 # this test checks that the 370-launch plan wires them into the right graph.
 GRAD_FLOOR = 5e-3 * (1.5 if os.environ.get('Y3_NO_FAST') else 1.0)   # generic kernel (Y3_NO_FAST=1): another summation order, another set of flips; largest excess seen 5.3e-3
+# conv_arithmetic 'x3' (the default since round 4): yet another rounding pattern, yet another set of flips.  Measured at 96 x 4: one
+# tensor (the beta gradient of a 576-pixel layer: a single leaky-relu flip is 5e-3 of it) at 5.76e-3 against an oracle noise of
+# 3.9e-5, i.e. an excess of 5.5e-3; every x3 kernel is closer to fp64 than its fp32-MFMA twin in isolation
+# (test_conv_x3_error_against_fp64_is_that_of_the_f32_instruction), so the floor is a statement about flips, not about arithmetic.
+GRAD_FLOOR_X3 = 1e-2
 ANCHORS = [(64, 384), (384, 64)]
 K = 2
 
@@ -41,7 +46,7 @@ def _check(got, ref32, ref64, what, **kw):
     assert err <= b, '%s: max err %.3e > bound %.3e' % (what, err, b)
 
 
-def _setup(img, n, seed, randomize_bn):
+def _setup(img, n, seed, randomize_bn, conv_arithmetic=None):
     from oracle import model as om
     from yolo3.model import YoloV3
     from test_gpu_kernels import _labels
@@ -52,7 +57,7 @@ def _setup(img, n, seed, randomize_bn):
         for p in params:
             if 'gamma' not in p:
                 p['W'] *= 0.02
-    yolo = YoloV3(n, [img, img, 3], K, ANCHORS, learning_rate=1e-3)
+    yolo = YoloV3(n, [img, img, 3], K, ANCHORS, learning_rate=1e-3, conv_arithmetic=conv_arithmetic)
     yolo.set_weights(params)
     g = torch.Generator().manual_seed(seed)
     images = torch.randn(n, 3, img, img, generator=g)
@@ -179,13 +184,20 @@ def test_bf16_layers_teacher_forced(img, n):
         assert bool(assert_fm), 'head %d' % j
 
 
-@pytest.mark.parametrize('img,n', [(96, 4), (416, 8)])
-def test_train_step_matches_oracle(img, n):
+@pytest.mark.parametrize('img,n,arith', [(96, 4, 'x3'), (96, 4, 'f32'), (416, 8, 'x3')])
+def test_train_step_matches_oracle(img, n, arith):
     """train_step(): forward with batch statistics, loss, full backward (dgrad/wgrad/BN/upsample), Keras Adam,
     moving-stat update.  Step 1 is compared tensor by tensor; step 2 only through its loss, because the first Adam
     step moves every weight by ~lr*sign(g) and the sign of a numerically-zero gradient is implementation noise.
-    (416, 8) is the benchmarked step (BASELINE.json configs[2]) at its full size."""
-    om, params, yolo, images, gts = _setup(img, n, 11, False)
+    (416, 8) is the benchmarked step (BASELINE.json configs[2]) at its full size, in the arithmetic bench.py times (x3 where the
+    model's policy uses it); (96, 4) runs both arithmetics.
+    HOW SHARP THIS IS: the gradient bound is 6 x the oracle's OWN fp32-vs-fp64 relative L2 distance + a floor.  At 416 x 8 that
+    distance is up to 1.6e-2 per tensor (median 1.1e-2) and the HIP step measures up to 1.5e-2 (round 3,
+    gpurun_out/train_step_grad_err_416_8.json): this is a 1e-2-class statement about the wiring of ~370 launches, NOT a 1e-5
+    statement about arithmetic -- it cannot see a 1 % error in one tensor.  The per-kernel tests of test_gpu_kernels.py
+    (2e-5 .. 1e-4 against fp64) are the ones that bound the arithmetic."""
+    om, params, yolo, images, gts = _setup(img, n, 11, False, conv_arithmetic=arith)
+    floor = GRAD_FLOOR_X3 if arith == 'x3' else GRAD_FLOOR
     gbs = n
     res = {}
     for dt in (torch.float32, torch.float64):
@@ -217,13 +229,13 @@ def test_train_step_matches_oracle(img, n):
         nb = np.linalg.norm(b) + 1e-30
         noise, err = np.linalg.norm(a - b) / nb, np.linalg.norm(g - b) / nb
         report.append((err, noise))
-        assert np.isfinite(g).all() and err <= 6.0 * noise + GRAD_FLOOR, 'grad tensor %d: rel L2 err %.3e (oracle fp32 noise %.3e)' % (i, err, noise)
+        assert np.isfinite(g).all() and err <= 6.0 * noise + floor, 'grad tensor %d: rel L2 err %.3e (oracle fp32 noise %.3e)' % (i, err, noise)
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
     if os.path.isdir(out_dir):      # what this run measured (the floor above is 2 x the largest excess seen: see GRAD_FLOOR)
         import json
         errs, noises = np.array([r[0] for r in report]), np.array([r[1] for r in report])
-        with open(os.path.join(out_dir, 'train_step_grad_err_%d_%d.json' % (img, n)), 'w') as fh:
-            json.dump(dict(tensors=len(report), max_rel_l2_err=float(errs.max()), median_rel_l2_err=float(np.median(errs)),
+        with open(os.path.join(out_dir, 'train_step_grad_err_%d_%d_%s.json' % (img, n, arith)), 'w') as fh:
+            json.dump(dict(tensors=len(report), conv_arithmetic=arith, max_rel_l2_err=float(errs.max()), median_rel_l2_err=float(np.median(errs)),
                            max_oracle_fp32_noise=float(noises.max()), median_oracle_fp32_noise=float(np.median(noises)),
                            max_excess_over_6x_noise=float((errs - 6.0 * noises).max())), fh)
     # moving statistics after the first forward depend on the initial weights only
@@ -358,4 +370,4 @@ def test_nonsquare_grayscale_three_anchors():
     for i, (gg, a, b) in enumerate(zip(flat, r32['grads'], r64['grads'])):
         a, b, gg = a.numpy().astype(np.float64), b.numpy(), np.asarray(gg, np.float64)
         nb = np.linalg.norm(b) + 1e-30
-        assert np.isfinite(gg).all() and np.linalg.norm(gg - b) / nb <= 6.0 * np.linalg.norm(a - b) / nb + GRAD_FLOOR, i
+        assert np.isfinite(gg).all() and np.linalg.norm(gg - b) / nb <= 6.0 * np.linalg.norm(a - b) / nb + GRAD_FLOOR_X3, i      # (default arithmetic: x3)

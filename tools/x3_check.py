@@ -18,6 +18,7 @@ ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--x3-only', action='store_true')
 ap.add_argument('--pad', type=int, default=0, help='pixel pitch of the activations = channels + pad floats')
+ap.add_argument('--stride2', action='store_true', help='time the five stride-2 forward layers instead')
 ap.add_argument('--all', action='store_true', help='every stride-1 shape of the net the x3 kernels take')
 args = ap.parse_args()
 N = args.batch
@@ -32,6 +33,35 @@ if args.all:
 lib = _hip.lib
 st = torch.cuda.current_stream().cuda_stream
 g = torch.Generator().manual_seed(0)
+
+if args.stride2:
+    for (hh, cin, cout) in ((416, 32, 64), (208, 64, 128), (104, 128, 256), (52, 256, 512), (26, 512, 1024)):
+        oh = hh // 2
+        xd = torch.randn(N, hh, hh, cin, device='cuda')
+        wd = torch.randn(3, 3, cin, cout, device='cuda') * 0.05
+        wtd = wd.permute(0, 1, 3, 2).contiguous()
+        b = torch.zeros(cout, device='cuda')
+        yo = torch.empty(N, oh, oh, cout, device='cuda')
+        X, Y = _hip.Tensor(xd.data_ptr(), N, hh, hh, cin, cin), _hip.Tensor(yo.data_ptr(), N, oh, oh, cout, cout)
+        m = N * oh * oh
+        ws = torch.zeros((256 << 20) // 4, device='cuda')
+
+        def f(x3):
+            _hip.check(lib.y3_conv2d_fwd(X, (wtd if x3 else wd).data_ptr(), b.data_ptr(), 3, 2, Y, _hip.EPI_LRELU | (_hip.CONV_X3 if x3 else 0), 0.2,
+                                         None, None, None, None, ws.data_ptr(), ws.numel() * 4, st), 'fwd s2')
+        evs = []
+        for x3 in (0, 1, 0, 1):
+            for _ in range(3):
+                f(x3)
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(args.iters):
+                f(x3)
+            e.record()
+            torch.cuda.synchronize()
+            evs.append(a.elapsed_time(e) / args.iters * 1e3)
+        print('stride-2 fwd %4d->%4d @%3d: f32 %6.1f / %6.1f us   x3 %6.1f / %6.1f us' % (cin, cout, hh, evs[0], evs[2], evs[1], evs[3]), flush=True)
+    sys.exit(0)
 
 
 def timeit(fns, iters):
