@@ -142,7 +142,7 @@ def timed_conv_pass(yolo, plan):
     gradient of a layer overlaps its data gradient, so summing durations would count that wall time twice."""
     from yolo3._hip import check
     conv_fns = {'y3_conv2d_fwd': 'conv2d_fwd', 'y3_conv2d_dgrad': 'conv2d_dgrad', 'y3_conv2d_dgrad_bn': 'conv2d_dgrad',
-                'y3_conv2d_wgrad': 'conv2d_wgrad'}
+                'y3_conv2d_wgrad': 'conv2d_wgrad', 'y3_conv2d_wgrad_x': 'conv2d_wgrad'}
     main = torch.cuda.current_stream()
     st = main.cuda_stream
     base = torch.cuda.Event(enable_timing=True)

@@ -103,6 +103,7 @@ int y3_conv2d_x3_ok(int m, int c, int ntaps, int nout);
  * items = workgroups.  Returns the workspace bytes (= y3_conv2d_fwd_workspace).  tests/planner_sweep.cpp replays the
  * kernel's item -> (tile, slice, slab, ticket) mapping from these numbers under AddressSanitizer. */
 size_t y3_conv2d_plan(int m, int cin, int ksize, int cout, int* out13);
+size_t y3_conv2d_plan_x(int m, int cin, int ksize, int cout, unsigned flags, int* out13);     /* the plan of a launch with `flags` (Y3_CONV_X3) */
 
 /*
  * Gradient w.r.t. the conv input (tape.gradient, model.py:496):
@@ -141,10 +142,19 @@ int y3_conv2d_dgrad_bn_tiles_x(const y3_tensor* ddst, int ksize, int stride, con
 int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride,
                     float* dw, void* workspace, size_t workspace_bytes, y3_stream_t stream);
 size_t y3_conv2d_wgrad_workspace(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride);
+/* The same with `flags`: Y3_CONV_X3 runs the contraction over the pixels as three bf16 pieces per operand (conv_wgrad_x3_kernel:
+ * both operands are activations, so both are split in the kernel; 128 x 128 tiles of the [K][Nout] gradient, fragments read with
+ * ds_read_b64_tr_b16).  Same operands, layouts, workspace contract and reduction order rules as y3_conv2d_wgrad; shapes:
+ * y3_conv2d_wgrad_x3_ok() (K = ksize^2 * Cin >= 128, Cout >= 128, Cin a power of two when ksize = 3). */
+int y3_conv2d_wgrad_x(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride,
+                      float* dw, unsigned flags, void* workspace, size_t workspace_bytes, y3_stream_t stream);
+size_t y3_conv2d_wgrad_workspace_x(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride, unsigned flags);
+int y3_conv2d_wgrad_x3_ok(int m, int cin, int ksize, int cout);
 /* Diagnostics: the kernel-gradient plan for m output pixels.  out8 = {bkr, bn, splits, chunk, tiles, in_kernel, grid,
  * pixel_table}: the m pixels are cut into `splits` runs of `chunk`; in_kernel = 1 when the last split of a tile reduces
  * the slabs inside the kernel (splits <= 8), else slab_reduce_kernel follows.  Returns the workspace bytes. */
 size_t y3_conv2d_wgrad_plan(int m, int cin, int ksize, int cout, int* out8);
+size_t y3_conv2d_wgrad_plan_x(int m, int cin, int ksize, int cout, unsigned flags, int* out8);
 
 /* wt_t[tap][co][ci] = wt[tap][ci][co] */
 int y3_transpose_weights(const float* wt, float* wt_t, int taps, int cin, int cout, y3_stream_t stream);

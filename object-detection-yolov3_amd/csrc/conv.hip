@@ -554,24 +554,6 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_multi_kernel(
 // ---------------------------------------------------------------------------
 // kernel gradient: out[z][k][n] = sum_{m in chunk z} A[m][k] * ddst[m][n]
 // ---------------------------------------------------------------------------
-#define Y3_WG_FANIN 8   // kernel-gradient slab reduction: fan-in of the in-kernel tree
-struct WgradArgs {
-    const float* src;
-    const float* ddst;
-    float* out;
-    unsigned long long tap_dhdw;
-    int H, W, C, logC, cmask, src_ld;
-    int OH, OW, sh, sw;
-    int dd_ld, Nout, K, M;
-    int chunk;  // pixels per split (multiple of BP)
-    int nbn, tiles, splits;
-    unsigned src_bytes, dd_bytes;  // extents for the buffer descriptors (out-of-range lanes read zeros)
-    int* tickets;  // splits > 1: one per (k-tile, n-tile), zero before the launch; `out` is then the slab area
-    float* dw;     // final destination [K][Nout]
-    int ohw, ntaps;
-    Y3Div dv_tiles, dv_nbn, dv_ohw, dv_ow;   // index decode without run-time divides (y3_make_div)
-};
-
 #ifndef Y3_WGRAD_WAVES_EU
 #define Y3_WGRAD_WAVES_EU 3   // waves per SIMD the register allocation aims at (140 VGPRs; 2 lets the compiler take 204)
 #endif
@@ -1210,10 +1192,12 @@ extern "C" int y3_conv2d_stats_tiles(int m, int cin, int ksize, int cout) { retu
 extern "C" size_t y3_conv2d_fwd_workspace(int m, int cin, int ksize, int cout) { return y3_conv2d_fwd_workspace_x(m, cin, ksize, cout, 0u); }
 
 // Diagnostics (include/yolo3hip.h): the plan behind y3_conv2d_fwd / stride-1 y3_conv2d_dgrad for an M x cout x (ksize^2 cin) GEMM
-extern "C" size_t y3_conv2d_plan(int m, int cin, int ksize, int cout, int* out13) {
+extern "C" size_t y3_conv2d_plan(int m, int cin, int ksize, int cout, int* out13) { return y3_conv2d_plan_x(m, cin, ksize, cout, 0u, out13); }
+extern "C" size_t y3_conv2d_plan_x(int m, int cin, int ksize, int cout, unsigned flags, int* out13) {
     const int taps = ksize * ksize, K = taps * cin;
-    const bool fast = fast_shape_ok(cin, cout, K, taps);
-    const ConvPlan pl = plan_conv(m, cout, K, fast);
+    const bool x3 = (flags & Y3_CONV_X3) && x3_shape_ok(cin, cout, K, taps);
+    const bool fast = x3 || fast_shape_ok(cin, cout, K, taps);
+    const ConvPlan pl = plan_conv(m, cout, K, fast, x3, taps);
     if (out13) {
         const int v[13] = {pl.t.bm, pl.t.bn, pl.t.bk, pl.tiles, pl.f, pl.s0, pl.s1, pl.chunk0, pl.chunk1,
                            pl.f * pl.s0 + (pl.tiles - pl.f) * pl.s1, pl.stats_tiles, fast ? 1 : 0, K / pl.t.bk};
@@ -1806,6 +1790,29 @@ static WgradPlan plan_wgrad(int K, int Nout, int M, int taps) {
     return w;
 }
 
+// The x3 kernel gradient (conv_x3.hip: conv_wgrad_x3_kernel): 128 x 128 tiles, two workgroups per CU (64 KB of LDS each), six
+// steps of 16 pixels per loop iteration.  ~480 workgroups per launch -- one round of the 512 slots.
+static bool wgrad_x3_shape_ok(int K, int Nout, int taps, int cin) {
+    return cin % 4 == 0 && K >= 128 && Nout >= 128 && (taps == 1 || y3_is_pow2(cin));
+}
+static WgradPlan plan_wgrad_x3(int K, int Nout, int M) {
+    WgradPlan w;
+    w.bkr = 128;
+    w.bn = 128;
+    w.tiles = y3_cdiv(K, 128) * y3_cdiv(Nout, 128);
+    static const int want = env_int("Y3_WGX3_WGS", 480);
+    int splits = want / w.tiles;
+    if (splits < 1) splits = 1;
+    const int maxs = y3_cdiv(M, 192);
+    if (splits > maxs) splits = maxs;
+    if (splits < y3_cdiv(M, Y3_WG_TABLE - 96)) splits = y3_cdiv(M, Y3_WG_TABLE - 96);       // a split's pixels fit the LDS pixel table
+    int chunk = y3_cdiv(M, splits);
+    chunk = y3_cdiv(chunk, 96) * 96;                  // whole loop iterations: six steps of 16 pixels
+    w.splits = y3_cdiv(M, chunk);
+    w.chunk = chunk;
+    return w;
+}
+
 // splits <= Y3_WG_FANIN: the reduction runs inside the kernel (one level: tickets + fragment-order slabs behind the header);
 // more splits: natural-layout slabs [split][K][Nout] + slab_reduce_kernel (measured: a multi-level in-kernel tree costs more
 // than the streaming reduce when every split is only a few K steps long)
@@ -1820,9 +1827,11 @@ static size_t wgrad_ws_bytes(const WgradPlan& w, int K, int Nout) {
 }
 
 // Diagnostics (include/yolo3hip.h): the plan behind y3_conv2d_wgrad
-extern "C" size_t y3_conv2d_wgrad_plan(int m, int cin, int ksize, int cout, int* out8) {
+extern "C" size_t y3_conv2d_wgrad_plan(int m, int cin, int ksize, int cout, int* out8) { return y3_conv2d_wgrad_plan_x(m, cin, ksize, cout, 0u, out8); }
+extern "C" size_t y3_conv2d_wgrad_plan_x(int m, int cin, int ksize, int cout, unsigned flags, int* out8) {
     const int taps = ksize * ksize, K = taps * cin;
-    const WgradPlan w = plan_wgrad(K, cout, m, taps);
+    const bool x3 = (flags & Y3_CONV_X3) && wgrad_x3_shape_ok(K, cout, taps, cin);
+    const WgradPlan w = x3 ? plan_wgrad_x3(K, cout, m) : plan_wgrad(K, cout, m, taps);
     if (out8) {
         const int v[8] = {w.bkr, w.bn, w.splits, w.chunk, w.tiles, wgrad_in_kernel(w) ? 1 : 0,
                           (w.splits >= 32 ? y3_cdiv(w.splits, 8) * 8 : w.splits) * w.tiles, Y3_WG_TABLE};
@@ -1831,16 +1840,28 @@ extern "C" size_t y3_conv2d_wgrad_plan(int m, int cin, int ksize, int cout, int*
     return wgrad_ws_bytes(w, K, cout);
 }
 
-extern "C" size_t y3_conv2d_wgrad_workspace(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride) {
+extern "C" int y3_conv2d_wgrad_x3_ok(int m, int cin, int ksize, int cout) {
+    return (m > 0 && wgrad_x3_shape_ok(ksize * ksize * cin, cout, ksize * ksize, cin)) ? 1 : 0;
+}
+extern "C" size_t y3_conv2d_wgrad_workspace_x(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride, unsigned flags) {
     (void)stride;
     const int K = ksize * ksize * src->c;
     const int M = ddst->n * ddst->h * ddst->w;
-    const WgradPlan w = plan_wgrad(K, ddst->c, M, ksize * ksize);
+    const bool x3 = (flags & Y3_CONV_X3) && wgrad_x3_shape_ok(K, ddst->c, ksize * ksize, src->c);
+    const WgradPlan w = x3 ? plan_wgrad_x3(K, ddst->c, M) : plan_wgrad(K, ddst->c, M, ksize * ksize);
     return wgrad_ws_bytes(w, K, ddst->c);
+}
+extern "C" size_t y3_conv2d_wgrad_workspace(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride) {
+    return y3_conv2d_wgrad_workspace_x(src, ddst, ksize, stride, 0u);
 }
 
 extern "C" int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride, float* dw, void* workspace,
                                size_t workspace_bytes, y3_stream_t stream) {
+    return y3_conv2d_wgrad_x(src, ddst, ksize, stride, dw, 0u, workspace, workspace_bytes, stream);
+}
+
+extern "C" int y3_conv2d_wgrad_x(const y3_tensor* src, const y3_tensor* ddst, int ksize, int stride, float* dw, unsigned flags, void* workspace,
+                                 size_t workspace_bytes, y3_stream_t stream) {
     if (int e = check_tensor(src, "conv2d_wgrad src")) return e;
     if (int e = check_tensor(ddst, "conv2d_wgrad ddst")) return e;
     Y3_CHECK_ARG(dw, "conv2d_wgrad: null dw");
@@ -1877,7 +1898,10 @@ extern "C" int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int 
         p.src_bytes = (unsigned)sb;
         p.dd_bytes = (unsigned)db;
     }
-    const WgradPlan w = plan_wgrad(p.K, p.Nout, p.M, taps);
+    Y3_CHECK_ARG((flags & ~Y3_CONV_X3) == 0, "conv2d_wgrad: only Y3_CONV_X3 allowed in flags");
+    const bool x3 = (flags & Y3_CONV_X3) != 0;
+    Y3_CHECK_ARG(!x3 || wgrad_x3_shape_ok(p.K, p.Nout, taps, src->c), "conv2d_wgrad: Y3_CONV_X3 does not take this shape (ask y3_conv2d_wgrad_x3_ok())");
+    const WgradPlan w = x3 ? plan_wgrad_x3(p.K, p.Nout, p.M) : plan_wgrad(p.K, p.Nout, p.M, taps);
     p.chunk = w.chunk;
     p.nbn = y3_cdiv(p.Nout, w.bn);
     p.ohw = OH * OW;
@@ -1906,7 +1930,12 @@ extern "C" int y3_conv2d_wgrad(const y3_tensor* src, const y3_tensor* ddst, int 
     // per CU (the occupancy their register budget aims at): step 18.21 -> 18.03 ms (tools/ab_wgrad_pad.sh, two rounds;
     // padding the 32 KB 64x64 variant as well: no further change).
     static const int pad40 = env_int("Y3_WGRAD_PAD40", 8192), pad32 = env_int("Y3_WGRAD_PAD32", 0);
-    if (w.bkr == 128 && w.bn == 128)
+    if (x3) {
+        if (!y3_wgrad_x3_launch(p, w.bkr, w.bn, grid.x, st)) {
+            y3_set_error("conv2d_wgrad: no x3 kernel for tile %dx%d", w.bkr, w.bn);
+            return Y3_EINVAL;
+        }
+    } else if (w.bkr == 128 && w.bn == 128)
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 16>), grid, dim3(256), 0, st, p);
     else if (w.bkr == 128 && w.bn == 64)
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 4, 1, 16>), grid, dim3(256), pad40, st, p);

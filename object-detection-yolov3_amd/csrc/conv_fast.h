@@ -101,6 +101,30 @@ __device__ __forceinline__ void y3_sgb_pairs() {   // COUNT x { MFMAS matrix ins
     }
 }
 
+// kernel gradient (conv.hip: conv_wgrad_kernel; conv_x3.hip: conv_wgrad_x3_kernel)
+#define Y3_WG_FANIN 8   // kernel-gradient slab reduction: fan-in of the in-kernel tree
+struct WgradArgs {
+    const float* src;
+    const float* ddst;
+    float* out;
+    unsigned long long tap_dhdw;
+    int H, W, C, logC, cmask, src_ld;
+    int OH, OW, sh, sw;
+    int dd_ld, Nout, K, M;
+    int chunk;  // pixels per split (multiple of BP)
+    int nbn, tiles, splits;
+    unsigned src_bytes, dd_bytes;  // extents for the buffer descriptors (out-of-range lanes read zeros)
+    int* tickets;  // splits > 1: one per (k-tile, n-tile), zero before the launch; `out` is then the slab area
+    float* dw;     // final destination [K][Nout]
+    int ohw, ntaps;
+    Y3Div dv_tiles, dv_nbn, dv_ohw, dv_ow;   // index decode without run-time divides (y3_make_div)
+};
+
+#ifndef Y3_WG_TABLE
+#define Y3_WG_TABLE 2048      // pixels per split the LDS pixel table holds (plan_wgrad keeps chunks below it)
+#endif
+bool y3_wgrad_x3_launch(const WgradArgs& p, int bkr, int bn, unsigned grid, hipStream_t st);
+
 // conv_x3.hip: launch of the x3 kernel for a planned tile (false: no kernel built for it)
 bool y3_x3_launch(const FastArgs& p, int bm, int bn, bool dense, int grid, hipStream_t st);
 bool y3_x3_tile_ok(int bm, int bn);

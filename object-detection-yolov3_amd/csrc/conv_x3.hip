@@ -649,6 +649,335 @@ static void x3_launch_tile(const FastArgs& p, bool dense, int grid, hipStream_t 
         hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WM, WN, false, false>), g, b, 0, st, p);
 }
 
+// ---------------------------------------------------------------------------
+// Kernel gradient on the same arithmetic:  dw[k][n] = sum_m A[m + off(tap)][c] * dz[m][n],  k = (tap, c).
+// The contraction runs over PIXELS, so both operands are activations (both are split in the kernel) and the MFMA wants, per
+// lane, 8 consecutive pixels of ONE channel -- the transpose of how NHWC data arrives.  The tiles are stored as they come,
+// [16 pixels][128 channels] bf16 per piece (256-byte rows, 16-byte chunks XOR-swizzled by the row: cdna_hip_programming.md T10
+// image (b)), and read with ds_read_b64_tr_b16, which hands every lane 4 pixels of its channel: two reads = one fragment.
+// One step = 16 pixels = one v_mfma_f32_32x32x16_bf16 per piece pair and block.  Everything around the loop -- the pixel table,
+// the split over pixel runs, the two reduction forms -- is conv_wgrad_kernel's (conv.hip).
+// Loop body: SIX steps (tile s: LDS buffer s & 1, register set s % 3: loads four steps ahead of their stores' step).
+// ---------------------------------------------------------------------------
+typedef short y3_s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ y3_bf16x8 x3_tr_pair(const unsigned short* a0, const unsigned short* a1) {
+    const y3_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((y3_s16x4 __attribute__((address_space(3)))*)(a0));
+    const y3_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((y3_s16x4 __attribute__((address_space(3)))*)(a1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(y3_bf16x8, v);
+}
+
+template <int BKR, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_x3_kernel(const WgradArgs p) {
+    constexpr int BP = 16;
+    constexpr int THREADS = 64 * WM * WN;
+    constexpr int TM = BKR / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
+    constexpr int KR4 = BKR / 4, BN4 = BN / 4;
+    static_assert(BKR == 128 && BN == 128 && THREADS == 256, "the swizzled [16][128] images and the loader are written for 128 x 128 tiles");
+    constexpr int A_LOADS = BP * KR4 / THREADS, B_LOADS = BP * BN4 / THREADS;      // 2 + 2
+    constexpr int PSTEP = THREADS / KR4;                                             // 8: pixel distance between a thread's loads
+    constexpr int PLANE = BP * 128;                  // u16 per piece plane (16 rows of 256 bytes)
+    constexpr int OPB = 3 * PLANE;                   // one operand, three pieces
+    constexpr int BUF = 2 * OPB;                     // A then B
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * BUF];
+    __shared__ uint2 pix[Y3_WG_TABLE];               // per pixel of this split: {byte offset of its (dh, dw) = (0, 0) source pixel, tap validity bits}
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int splits = p.splits, tiles = p.tiles, nbn = p.nbn, chunk = p.chunk, aM = p.M, ohw = p.ohw, OW = p.OW, aH = p.H, aW = p.W;
+    int src_ld = p.src_ld, csh = p.sh, csw = p.sw, ntaps = p.ntaps;
+    unsigned dt_m = p.dv_tiles.mul, dn_m = p.dv_nbn.mul, dohw_m = p.dv_ohw.mul, dow_m = p.dv_ow.mul;
+    int dt_s = p.dv_tiles.shift, dn_s = p.dv_nbn.shift, dohw_s = p.dv_ohw.shift, dow_s = p.dv_ow.shift;
+    unsigned dhdw_lo = (unsigned)p.tap_dhdw, dhdw_hi = (unsigned)(p.tap_dhdw >> 32);
+    Y3_PIN_S(splits); Y3_PIN_S(tiles); Y3_PIN_S(nbn); Y3_PIN_S(chunk); Y3_PIN_S(aM); Y3_PIN_S(ohw); Y3_PIN_S(OW); Y3_PIN_S(aH); Y3_PIN_S(aW);
+    Y3_PIN_S(src_ld); Y3_PIN_S(csh); Y3_PIN_S(csw); Y3_PIN_S(ntaps);
+    Y3_PIN_S(dt_m); Y3_PIN_S(dn_m); Y3_PIN_S(dohw_m); Y3_PIN_S(dow_m); Y3_PIN_S(dt_s); Y3_PIN_S(dn_s); Y3_PIN_S(dohw_s); Y3_PIN_S(dow_s);
+    Y3_PIN_S(dhdw_lo); Y3_PIN_S(dhdw_hi);
+    const Y3Div dv_tiles = {dt_m, dt_s}, dv_nbn = {dn_m, dn_s}, dv_ohw = {dohw_m, dohw_s}, dv_ow = {dow_m, dow_s};
+    const unsigned long long tap_dhdw = ((unsigned long long)dhdw_hi << 32) | dhdw_lo;
+    int split, bid;
+    if (splits >= 32) {       // (block -> (pixel run, tile): conv_wgrad_kernel)
+        const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+        const int q = y3_div(jx, dv_tiles);
+        split = q * 8 + xcd;
+        bid = jx - q * tiles;
+    } else {
+        split = y3_div((int)blockIdx.x, dv_tiles);
+        bid = y3_xcd_remap((int)blockIdx.x - split * tiles, tiles);
+    }
+    if (split >= splits) return;
+    const int bk = y3_div(bid, dv_nbn), bn = bid - bk * nbn;
+    const int k0 = bk * BKR, n0 = bn * BN;
+    const int mbeg = split * chunk;
+    const int mend = min(aM, mbeg + chunk);
+    const int nsteps = (mend > mbeg) ? (mend - mbeg + BP - 1) / BP : 0;
+    {
+        for (int pl = tid; pl < nsteps * BP; pl += THREADS) {
+            const int m = mbeg + pl;
+            unsigned off = 0, msk = 0;
+            if (m < mend) {
+                const int n = y3_div(m, dv_ohw);
+                const int r = m - n * ohw;
+                const int oh = y3_div(r, dv_ow), ow = r - oh * OW;
+                const int ih0 = oh * csh, iw0 = ow * csw;
+                off = (unsigned)(((n * aH + ih0) * aW + iw0) * src_ld) * 4u;
+                for (int t = 0; t < ntaps; ++t) {
+                    const int code = (int)((tap_dhdw >> (4 * t)) & 15ull);
+                    const int ih = ih0 + (code & 3) - 1, iw = iw0 + (code >> 2) - 1;
+                    if ((unsigned)ih < (unsigned)aH && (unsigned)iw < (unsigned)aW) msk |= 1u << t;
+                }
+            }
+            pix[pl] = make_uint2(off, msk);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ddst), 0, p.dd_bytes, 0x00020000);
+    // loaders: thread -> (pixel tid / 32 (+ 8 per load), channel quad tid % 32) of both [16][128] tiles
+    const int a_kv = tid % KR4;
+    const int ak = k0 + a_kv * 4;
+    const bool ak_ok = ak < p.K;
+    const int atap = ak_ok ? (ak >> p.logC) : 0;
+    const int ac = ak & p.cmask;
+    const int acode = (int)((tap_dhdw >> (4 * atap)) & 15ull);
+    const int a_tapoff = ((((acode & 3) - 1) * p.W + ((acode >> 2) - 1)) * p.src_ld + ac) * 4;
+    const unsigned a_bit = ak_ok ? 1u << atap : 0u;
+    const int pp0 = tid / KR4;
+    const int bnn = n0 + a_kv * 4;
+    const bool bn_ok = bnn < p.Nout;
+    const unsigned b_lane = (unsigned)(bnn * 4);
+    // LDS image of a tile: 256-byte pixel rows, 16-byte chunk ch of row r at 16 * (ch ^ (((r & 3) << 2) | ((r >> 2) & 3)))
+    auto swz = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
+    int st_off[A_LOADS];       // u16 index of this thread's 8-byte store slot (same for both operands)
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int row = pp0 + i * PSTEP;
+        st_off[i] = row * 128 + 8 * ((a_kv >> 1) ^ swz(row)) + 4 * (a_kv & 1);
+    }
+    // transposed fragment reads: 16-lane group g = lane / 16 takes pixels 8 (g / 2) + 4 j .. + 3 of channels 16 (g & 1) .. + 15 of
+    // its 32-channel block; lane 4 q + pc of the group supplies row q, columns 4 pc .. 4 pc + 3
+    int fr_a[MB][2], fr_b[NB][2];
+    {
+        const int g = lane >> 4, li = lane & 15, q = li >> 2, pc = li & 3, h = g >> 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 8 * h + 4 * j + q;
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int c = wm * TM + i * 32 + 16 * (g & 1) + 4 * pc;
+                fr_a[i][j] = row * 128 + 8 * ((c >> 3) ^ swz(row)) + (c & 4);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int c = wn * TN + i * 32 + 16 * (g & 1) + 4 * pc;
+                fr_b[i][j] = row * 128 + 8 * ((c >> 3) ^ swz(row)) + (c & 4);
+            }
+        }
+    }
+
+    f32x4 ra[3][A_LOADS], rb[3][B_LOADS];
+    uint2 pe[A_LOADS];
+    auto tload = [&](int step) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) pe[i] = pix[step * BP + pp0 + i * PSTEP];
+    };
+    auto gload_a = [&](auto I, int step, auto S) {
+        constexpr int i = decltype(I)::value;
+        const bool ok = ((pe[i].y & a_bit) != 0) & (step < nsteps);
+        ra[decltype(S)::value][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, ok ? pe[i].x + (unsigned)a_tapoff : Y3_OOB, 0, 0);
+    };
+    auto gload_b = [&](auto I, int step, auto S) {
+        constexpr int i = decltype(I)::value;
+        const int m = mbeg + step * BP + pp0 + i * PSTEP;
+        const bool ok = (m < mend) & bn_ok;
+        rb[decltype(S)::value][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dd, ok ? (unsigned)(m * p.dd_ld) * 4u + b_lane : Y3_OOB, 0, 0);
+    };
+    X3Pk pk = {0, 0};
+    auto sub = [&](auto S, auto E, int buf) {      // sub-step E (0 .. 15) of splitting tile set S into LDS buffer buf
+        constexpr int set = decltype(S)::value, e = decltype(E)::value, w = e / 4, sb = e % 4;
+        if constexpr (w < A_LOADS) {
+            unsigned short* d = &lds[buf * BUF + st_off[w]];
+            x3_split_sub<sb>(ra[set][w], pk, d, d + PLANE, d + 2 * PLANE);
+        } else {
+            unsigned short* d = &lds[buf * BUF + OPB + st_off[w - A_LOADS]];
+            x3_split_sub<sb>(rb[set][w - A_LOADS], pk, d, d + PLANE, d + 2 * PLANE);
+        }
+    };
+    y3_bf16x8 FA[2][3][MB], FB[2][3][NB];
+    auto read_a = [&](auto F, auto PC, int i, int buf) {
+        const unsigned short* b = &lds[buf * BUF + decltype(PC)::value * PLANE];
+        FA[decltype(F)::value][decltype(PC)::value][i] = x3_tr_pair(b + fr_a[i][0], b + fr_a[i][1]);
+    };
+    auto read_b = [&](auto F, auto PC, int j, int buf) {
+        const unsigned short* b = &lds[buf * BUF + OPB + decltype(PC)::value * PLANE];
+        FB[decltype(F)::value][decltype(PC)::value][j] = x3_tr_pair(b + fr_b[j][0], b + fr_b[j][1]);
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    constexpr int NW = A_LOADS + B_LOADS;
+    __syncthreads();                       // pixel table complete
+    if (nsteps > 0) {
+        constexpr int NMG = MB * NB, NM = 6 * NMG, SB = Y3_X3_GB * NMG, SP = NM - SB;
+        constexpr int NR1 = NB + MB + MB, NS = NW * 4;
+        constexpr int NR2 = MB + NB + NB, RS2 = (NR2 + 1) / 2;
+        static_assert(NR1 <= SB && RS2 + (NW + 1) / 2 + 1 <= SP, "not enough MFMA slots for the events of a step");
+        auto step = [&](auto U, int s6) {       // step U of the six-step body; s6 = first step of the body
+            constexpr int u = decltype(U)::value, cur = u & 1;
+            using F = std::integral_constant<int, cur>;
+            using G = std::integral_constant<int, cur ^ 1>;
+            using RS = std::integral_constant<int, (u + 1) % 3>;      // register set stored (tile u + 1) and reloaded (tile u + 4) in this step
+            const int st = s6 + u;
+            y3_for_each_ic(std::make_integer_sequence<int, NM>{}, [&](auto Mi) {
+                constexpr int m = decltype(Mi)::value;
+                constexpr int g = m / NMG, i = (m % NMG) / NB, j = m % NB;
+                constexpr int pa = g < 3 ? 0 : (g < 5 ? 1 : 2), pb = g < 3 ? g : (g == 3 ? 0 : (g == 4 ? 1 : 0));
+                if constexpr (m == SB) {
+                    y3_lds_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[cur][pa][i], FB[cur][pb][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (m < SB) {
+                    if constexpr (m < NB)
+                        read_b(F{}, C2{}, m, cur);
+                    else if constexpr (m < NB + MB)
+                        read_a(F{}, C1{}, m - NB, cur);
+                    else if constexpr (m < NR1)
+                        read_a(F{}, C2{}, m - NB - MB, cur);
+                    constexpr int s0 = m * NS / SB, s1 = (m + 1) * NS / SB;
+                    y3_for_each_ic(std::make_integer_sequence<int, s1 - s0>{}, [&](auto D) { sub(RS{}, std::integral_constant<int, s0 + decltype(D)::value>{}, cur ^ 1); });
+                } else {
+                    constexpr int q = m - SB;
+                    if constexpr (q < RS2) {
+                        y3_for_each_ic(std::make_integer_sequence<int, 2>{}, [&](auto D) {
+                            constexpr int r = q * 2 + decltype(D)::value;
+                            if constexpr (r < MB)
+                                read_a(G{}, C0{}, r, cur ^ 1);
+                            else if constexpr (r < MB + NB)
+                                read_b(G{}, C0{}, r - MB, cur ^ 1);
+                            else if constexpr (r < NR2)
+                                read_b(G{}, C1{}, r - MB - NB, cur ^ 1);
+                        });
+                    } else if constexpr (q < RS2 + (NW + 1) / 2) {
+                        y3_for_each_ic(std::make_integer_sequence<int, 2>{}, [&](auto D) {
+                            constexpr int e = (q - RS2) * 2 + decltype(D)::value;
+                            if constexpr (e < A_LOADS)
+                                gload_a(std::integral_constant<int, e>{}, st + 4, RS{});
+                            else if constexpr (e < NW)
+                                gload_b(std::integral_constant<int, e - A_LOADS>{}, st + 4, RS{});
+                        });
+                    } else if constexpr (q == RS2 + (NW + 1) / 2) {
+                        tload(min(st + 5, nsteps - 1));       // table entries of the next step's loads
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        auto load_tile = [&](int step, auto S) {
+            tload(min(step, nsteps - 1));
+            y3_for_each_ic(std::make_integer_sequence<int, A_LOADS>{}, [&](auto I) { gload_a(I, step, S); });
+            y3_for_each_ic(std::make_integer_sequence<int, B_LOADS>{}, [&](auto I) { gload_b(I, step, S); });
+        };
+        load_tile(0, C0{});
+        y3_for_each_ic(std::make_integer_sequence<int, NW * 4>{}, [&](auto E) { sub(C0{}, E, 0); });
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);       // (pinned order: the set the loop consumes first is the oldest, see conv_x3_body)
+        load_tile(1, C1{});
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(2, C2{});
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(3, C0{});
+        __builtin_amdgcn_sched_barrier(0);
+        tload(min(4, nsteps - 1));
+#pragma unroll
+        for (int i = 0; i < MB; ++i) read_a(C0{}, C0{}, i, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            read_b(C0{}, C0{}, j, 0);
+            read_b(C0{}, C1{}, j, 0);
+        }
+        // six uniform steps per iteration; steps beyond the split's pixels are dead (their loads return zeros)
+        for (int s6 = 0; s6 < nsteps; s6 += 6)
+            y3_for_each_ic(std::make_integer_sequence<int, 6>{}, [&](auto U) { step(U, s6); });
+    }
+    __syncthreads();                       // (the reduction below reuses the stage as a flag word)
+
+    constexpr int R4 = MB * NB * 4;
+    const int l31 = lane & 31, lh = lane >> 5;
+    if (p.splits > 1 && p.tickets != nullptr) {
+        // in-kernel reduction over <= Y3_WG_FANIN pixel runs: conv_wgrad_kernel's hand-off (slab[tile][split][r4][thread], tickets)
+        const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x7ffffff0, 0x00020000);
+        const unsigned item_bytes = (unsigned)(R4 * THREADS * 16);
+        int* flag = reinterpret_cast<int*>(&lds[0]);
+        const int count = p.splits;
+        const unsigned level0 = (unsigned)(bid * count) * item_bytes + (unsigned)tid * 16u;
+        const unsigned base = level0 + (unsigned)split * item_bytes;
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f32x4 v = {acc[i][j][4 * r], acc[i][j][4 * r + 1], acc[i][j][4 * r + 2], acc[i][j][4 * r + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, base, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            int* tk = p.tickets + bid;
+            const int old = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == count - 1;
+            if (last) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag) return;
+#pragma unroll 1
+        for (int z = 0; z < count; ++z) {
+            const unsigned base2 = level0 + (unsigned)z * item_bytes;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, base2, (unsigned)(((i * NB + j) * 4 + r) * THREADS * 16), 16 /* sc1 */);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * r + e] = z == 0 ? v[e] : acc[i][j][4 * r + e] + v[e];
+                    }
+        }
+    }
+    float* out = p.tickets != nullptr ? p.dw : p.out + (p.splits > 1 ? (long long)split * p.K * p.Nout : 0ll);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * TN + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (k < p.K && n < p.Nout) out[(long long)k * p.Nout + n] = acc[i][j][r];
+            }
+    }
+}
+
+bool y3_wgrad_x3_launch(const WgradArgs& p, int bkr, int bn, unsigned grid, hipStream_t st) {
+    if (bkr != 128 || bn != 128) return false;
+    hipLaunchKernelGGL((conv_wgrad_x3_kernel<128, 128, 2, 2>), dim3(grid), dim3(256), 0, st, p);
+    return true;
+}
+
 // Tiles this file is built for (conv.hip plans with them): false if (bm, bn) is not one of them.
 bool y3_x3_tile_ok(int bm, int bn) { return bm == 128 && (bn == 128 || bn == 64); }
 
@@ -668,7 +997,11 @@ bool y3_x3p_ok(const FastArgs& p, int bm, int bn, bool dense) {
 }
 
 bool y3_x3_launch(const FastArgs& p, int bm, int bn, bool dense, int grid, hipStream_t st) {
+#ifdef Y3_DEV
     static const int no_patch = getenv("Y3_X3_NO_PATCH") ? atoi(getenv("Y3_X3_NO_PATCH")) : 0;      // development: the im2col-order kernel for every launch
+#else
+    const int no_patch = 0;
+#endif
     if (!no_patch && y3_x3p_ok(p, bm, bn, dense)) {
         const dim3 g(grid), b(256);
         if (p.bn_a)

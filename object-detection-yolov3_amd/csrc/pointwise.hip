@@ -184,14 +184,19 @@ struct BnbPlan {
 };
 static bool plan_bnb(long long m, int c, BnbPlan* p) {
     if (c < 4 || c > 1024 || (c & 3)) return false;
-    static const int lcap = getenv("Y3_BNB_LC") ? atoi(getenv("Y3_BNB_LC")) : 8;      // 8 float4 lanes = one 128-byte line per row
+#ifdef Y3_DEV      // development switches (make DEV=1): the product library reads neither
+    static const int lcap = getenv("Y3_BNB_LC") ? atoi(getenv("Y3_BNB_LC")) : 8;
+    static const int blocks = getenv("Y3_BNB_BLOCKS") ? atoi(getenv("Y3_BNB_BLOCKS")) : Y3_BNB_BLOCKS;
+#else
+    const int lcap = 8;                  // 8 float4 lanes = one 128-byte line per row
+    const int blocks = Y3_BNB_BLOCKS;
+#endif
     p->lc = c / 4 < lcap ? c / 4 : lcap;
     if (p->lc & (p->lc - 1)) return false;
     p->sw = 4 * p->lc;
     if (c % p->sw) return false;
     p->slices = c / p->sw;
     long long parts = y3_cdiv(m, (long long)(256 / p->lc) * 4);
-    static const int blocks = getenv("Y3_BNB_BLOCKS") ? atoi(getenv("Y3_BNB_BLOCKS")) : Y3_BNB_BLOCKS;
     int cap = (blocks < Y3_BNB_BLOCKS ? blocks : Y3_BNB_BLOCKS) / p->slices;
     if (cap < 1) cap = 1;
     if (parts > cap) parts = cap;

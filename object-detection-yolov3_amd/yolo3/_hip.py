@@ -55,6 +55,9 @@ SIGNATURES = {
     'y3_conv2d_dgrad_bn_tiles': (i32, [TP, i32, i32, TP]),
     'y3_conv2d_wgrad': (i32, [TP, TP, i32, i32, fp, vp, sz, vp]),
     'y3_conv2d_wgrad_workspace': (sz, [TP, TP, i32, i32]),
+    'y3_conv2d_wgrad_x': (i32, [TP, TP, i32, i32, fp, u32, vp, sz, vp]),
+    'y3_conv2d_wgrad_workspace_x': (sz, [TP, TP, i32, i32, u32]),
+    'y3_conv2d_wgrad_x3_ok': (i32, [i32, i32, i32, i32]),
     'y3_transpose_weights': (i32, [fp, fp, i32, i32, i32, vp]),
     'y3_transpose_weights_batched': (i32, [fp, fp, ip, i32, i32, vp]),
     'y3_bn_stats_finalize': (i32, [fp, i32, i32, i32, fp, fp, f32, f32, fp, fp, fp, fp, fp, fp, vp]),
@@ -96,6 +99,8 @@ SIGNATURES = {
     'y3_allreduce_sum_f32': (i32, [vp, fp, sz, vp]),
     'y3_conv2d_plan': (sz, [i32, i32, i32, i32, C.POINTER(C.c_int)]),
     'y3_conv2d_wgrad_plan': (sz, [i32, i32, i32, i32, C.POINTER(C.c_int)]),
+    'y3_conv2d_plan_x': (sz, [i32, i32, i32, i32, u32, C.POINTER(C.c_int)]),
+    'y3_conv2d_wgrad_plan_x': (sz, [i32, i32, i32, i32, u32, C.POINTER(C.c_int)]),
     'y3_comm_info': (i32, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'y3_comm_destroy': (i32, [vp]),
     'y3_zscore': (i32, [fp, fp, i32, sz, vp, vp]),

@@ -233,7 +233,7 @@ class _Plan:
         act = torch.bfloat16 if bf else torch.float32      # activation storage type after the first layer
         self.in_nchw = torch.zeros(N, C, H, W, dtype=torch.float32, device=dev)
         self.ops = []      # high-level records for the backward emission
-        self.x3_fwd, self.x3_dgrad = [], []     # layers whose forward / data gradient runs the x3 kernels (bench.py: work per arithmetic)
+        self.x3_fwd, self.x3_dgrad, self.x3_wgrad = [], [], []     # layers whose forward / data gradient / kernel gradient runs the x3 kernels (bench.py: work per arithmetic)
         self.layer_out = []  # output activation of every conv_layer, creation order (debug / tests)
         li = [0]
 
@@ -428,7 +428,8 @@ class _Plan:
                 sp = specs[op[1]]
                 src = op[2]
                 dd = op[3]
-                need = lib.y3_conv2d_wgrad_workspace(src.v, view(self.dz, dd.n, dd.h, dd.w, sp.cout), sp.k, sp.s)
+                need = lib.y3_conv2d_wgrad_workspace_x(src.v, view(self.dz, dd.n, dd.h, dd.w, sp.cout), sp.k, sp.s,
+                                                       CONV_X3 if (op[0] == 'conv_layer' and mdl.x3_wgrad(sp, dd.m)) else 0)
                 wg_need = max(wg_need, int(need))
         self.wg_ws = torch.zeros(max(wg_need // 4, 4), dtype=torch.float32, device=mdl.device)      # tickets + slabs, zeroed once
         self.wg_ws_bytes = wg_need
@@ -549,16 +550,19 @@ class _Plan:
                     if two and dz_busy[slot] is not None:
                         self.bwd.append(('main_wait', dz_busy[slot]))
                     self._emit(self.bwd, lib.y3_bn_bwd_apply, dy.v, a.v, coef, LRELU_ALPHA, dz.v)
+                wx3 = CONV_X3 if mdl.x3_wgrad(sp, a.m) else 0      # kernel gradient on the x3 arithmetic (both operands are activations: no weight copy involved)
+                if wx3:
+                    self.x3_wgrad.append(i)
                 if two:
                     self.events += [torch.cuda.Event(), torch.cuda.Event()]
                     e_dz, e_wg = len(self.events) - 2, len(self.events) - 1
                     self.bwd.append(('record', e_dz))
-                    wargs = (src.v, dz.v, sp.k, sp.s, gptr(sp.w_off), self.wg_ws.data_ptr(), self.wg_ws_bytes)
+                    wargs = (src.v, dz.v, sp.k, sp.s, gptr(sp.w_off), wx3, self.wg_ws.data_ptr(), self.wg_ws_bytes)
                     self.keep.append(wargs)
-                    self.bwd.append(('side_call', (lib.y3_conv2d_wgrad, wargs, e_dz, e_wg)))
+                    self.bwd.append(('side_call', (lib.y3_conv2d_wgrad_x, wargs, e_dz, e_wg)))
                     dz_busy[slot] = e_wg
                 else:
-                    self._emit(self.bwd, lib.y3_conv2d_wgrad, src.v, dz.v, sp.k, sp.s, gptr(sp.w_off), self.wg_ws.data_ptr(), self.wg_ws_bytes)
+                    self._emit(self.bwd, lib.y3_conv2d_wgrad_x, src.v, dz.v, sp.k, sp.s, gptr(sp.w_off), wx3, self.wg_ws.data_ptr(), self.wg_ws_bytes)
                 if src is not first_src:
                     ds = self._grad_of(src)
                     # x3 data gradient: the kernel wants K (= this layer's output channels) contiguous per column: the Keras arena
@@ -742,6 +746,13 @@ class YoloV3:
 
     def x3_dgrad(self, sp, m_in):
         return self._x3_policy(sp.cout, sp.k * sp.k, sp.cin_pad, m_in, sp.s, False)
+
+    def x3_wgrad(self, sp, m_out):
+        if self.conv_arithmetic == 'f32' or not lib.y3_conv2d_wgrad_x3_ok(m_out, sp.cin_pad, sp.k, sp.cout):
+            return False
+        # measured (tools/x3_check.py --wgrad): every 3x3 layer with >= 128 output channels 1.3-1.7x, stride 2 included; the 1x1
+        # layers 1.1-1.2x at 52^2 / 26^2 and slower at 13^2
+        return self.conv_arithmetic == 'x3-all' or sp.k == 3 or m_out >= 5000
 
     # ---- construction helpers --------------------------------------------------
     def _init_weights(self, seed):

@@ -37,15 +37,22 @@ static int xcd_remap(int orig, int nwg) {
 
 static const size_t HEADER = 256 * 1024;      // yolo3hip.h workspace contract: 65 536 tickets in front of the slabs
 
-static void check_conv_plan(const char* what, int m, int cin, int k, int cout) {
+static void check_conv_plan(const char* what, int m, int cin, int k, int cout, unsigned flags = 0) {
     int o[13];
-    const size_t ws = y3_conv2d_plan(m, cin, k, cout, o);
+    const size_t ws = y3_conv2d_plan_x(m, cin, k, cout, flags, o);
     const int bm = o[0], bn = o[1], bk = o[2], tiles = o[3], f = o[4], s0 = o[5], s1 = o[6], c0 = o[7], c1 = o[8], grid = o[9],
               stats_tiles = o[10], fast = o[11], nk = o[12];
     printf("conv %s m=%d cin=%d k=%d cout=%d bm=%d bn=%d bk=%d tiles=%d f=%d s0=%d s1=%d c0=%d c1=%d grid=%d stats=%d fast=%d nk=%d ws=%zu\n", what, m,
            cin, k, cout, bm, bn, bk, tiles, f, s0, s1, c0, c1, grid, stats_tiles, fast, nk, ws);
-    REQUIRE(ws == y3_conv2d_fwd_workspace(m, cin, k, cout), "%s: plan and workspace query disagree", what);
-    REQUIRE(stats_tiles == y3_conv2d_stats_tiles(m, cin, k, cout), "%s: plan and stats_tiles query disagree", what);
+    REQUIRE(ws == y3_conv2d_fwd_workspace_x(m, cin, k, cout, flags), "%s: plan and workspace query disagree", what);
+    REQUIRE(stats_tiles == y3_conv2d_stats_tiles_x(m, cin, k, cout, flags), "%s: plan and stats_tiles query disagree", what);
+    if (flags & Y3_CONV_X3) {
+        REQUIRE(bm == 128 && (bn == 128 || bn == 64), "%s: x3 tile %dx%d", what, bm, bn);
+        // the patch kernel's loop body is 18 K steps (two 16-channel chunks of nine taps): split 3x3 launches are cut in such units
+        if (k == 3 && s0 > 1) REQUIRE(c0 % 18 == 0, "%s: x3 slice of %d K steps", what, c0);
+        if (k == 3 && s1 > 1 && f < tiles) REQUIRE(c1 % 18 == 0, "%s: x3 remainder slice of %d K steps", what, c1);
+        REQUIRE(c0 % 2 == 0 && c1 % 2 == 0, "%s: x3 slices are pairs of steps (%d, %d)", what, c0, c1);
+    }
     REQUIRE(bk == 16 && (bm == 64 || bm == 128 || bm == 256) && (bn == 32 || bn == 64 || bn == 128), "%s: tile %dx%dx%d", what, bm, bn, bk);
     REQUIRE(tiles == cdiv(m, bm) * cdiv(cout, bn) && stats_tiles == cdiv(m, bm), "%s: tile count", what);
     REQUIRE(f >= 0 && f <= tiles && s0 >= 1 && s1 >= 1 && c0 >= 1 && c1 >= 1, "%s: split parameters", what);
@@ -93,15 +100,16 @@ static void check_conv_plan(const char* what, int m, int cin, int k, int cout) {
     for (int t = 0; t < tiles; ++t) REQUIRE(slices[t] == (t < f ? s0 : s1), "%s: tile %d got %d slices", what, t, (int)slices[t]);
 }
 
-static void check_wgrad_plan(int m, int cin, int k, int cout) {
+static void check_wgrad_plan(int m, int cin, int k, int cout, unsigned flags = 0) {
     int o[8];
-    const size_t ws = y3_conv2d_wgrad_plan(m, cin, k, cout, o);
+    const size_t ws = y3_conv2d_wgrad_plan_x(m, cin, k, cout, flags, o);
     const int bkr = o[0], bn = o[1], splits = o[2], chunk = o[3], tiles = o[4], in_kernel = o[5], grid = o[6], table = o[7];
     const long long K = (long long)k * k * cin;
-    printf("wgrad m=%d cin=%d k=%d cout=%d bkr=%d bn=%d splits=%d chunk=%d tiles=%d in_kernel=%d grid=%d ws=%zu\n", m, cin, k, cout, bkr, bn, splits,
+    printf("wgrad%s m=%d cin=%d k=%d cout=%d bkr=%d bn=%d splits=%d chunk=%d tiles=%d in_kernel=%d grid=%d ws=%zu\n", flags ? "_x3" : "", m, cin, k, cout, bkr, bn, splits,
            chunk, tiles, in_kernel, grid, ws);
     y3_tensor src = {nullptr, 1, 1, m, cin, cin}, dd = {nullptr, 1, 1, m, cout, cout};
-    REQUIRE(ws == y3_conv2d_wgrad_workspace(&src, &dd, k, 1), "wgrad: plan and workspace query disagree");
+    REQUIRE(ws == y3_conv2d_wgrad_workspace_x(&src, &dd, k, 1, flags), "wgrad: plan and workspace query disagree");
+    if (flags & Y3_CONV_X3) REQUIRE(bkr == 128 && bn == 128 && chunk % 96 == 0, "wgrad x3: tile %dx%d, %d pixels per split (six steps of 16 per loop iteration)", bkr, bn, chunk);
     REQUIRE((bkr == 64 || bkr == 128) && (bn == 32 || bn == 64 || bn == 128), "wgrad: tile %dx%d", bkr, bn);
     REQUIRE(tiles == cdiv(K, bkr) * cdiv(cout, bn), "wgrad: tile count");
     REQUIRE(splits >= 1 && chunk >= 16 && chunk % 16 == 0, "wgrad: splits=%d chunk=%d", splits, chunk);
@@ -168,12 +176,22 @@ int main(int argc, char** argv) {
         snprintf(name, sizeof name, "fwd[%zu]", i);
         check_conv_plan(name, m, l.cin, l.k, l.cout);
         check_wgrad_plan(m, l.cin, l.k, l.cout);
+        if (y3_conv2d_x3_ok(m, l.cin, l.k * l.k, l.cout)) {      // the same launch on the x3 kernels (Y3_CONV_X3)
+            snprintf(name, sizeof name, "fwd_x3[%zu]", i);
+            check_conv_plan(name, m, l.cin, l.k, l.cout, Y3_CONV_X3);
+        }
+        if (y3_conv2d_wgrad_x3_ok(m, l.cin, l.k, l.cout)) check_wgrad_plan(m, l.cin, l.k, l.cout, Y3_CONV_X3);
         if (i == 0) continue;                    // the first layer has no data gradient
         const int in = o * l.s, mi = batch * in * in;
         y3_tensor dd = {nullptr, batch, o, o, l.cout, (l.cout + 3) / 4 * 4}, ds = {nullptr, batch, in, in, l.cin, l.cin};
         if (l.s == 1) {
             snprintf(name, sizeof name, "dgrad[%zu]", i);
             check_conv_plan(name, mi, l.cout, l.k, l.cin);
+            if (y3_conv2d_x3_ok(mi, l.cout, l.k * l.k, l.cin)) {
+                snprintf(name, sizeof name, "dgrad_x3[%zu]", i);
+                check_conv_plan(name, mi, l.cout, l.k, l.cin, Y3_CONV_X3);
+                REQUIRE(y3_conv2d_dgrad_workspace_x(&dd, l.k, l.s, &ds, Y3_CONV_X3) == y3_conv2d_fwd_workspace_x(mi, l.cout, l.k, l.cin, Y3_CONV_X3), "dgrad_x3[%zu]: workspace queries disagree", i);
+            }
         } else {
             for (int nt = 1; nt <= 4; nt *= 2) {          // parity classes of a 3x3 stride-2 data gradient: 1, 2, 2, 4 taps
                 snprintf(name, sizeof name, "dgrad[%zu]/taps%d", i, nt);

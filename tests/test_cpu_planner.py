@@ -79,6 +79,7 @@ def test_product_build_ignores_development_switches(sweeps):
     exe, _ = sweeps
     base = _run(exe, [8, 416])
     assert _run(exe, [8, 416], {'Y3_TILE': '64,64,16', 'Y3_RSPLIT': '0', 'Y3_SPLITK_WGS': '500', 'Y3_WGRAD_WAVES': '1024', 'Y3_PIPE': '1'}) == base
+    assert _run(exe, [8, 416], {'Y3_X3_WGS': '1000', 'Y3_X3_KS': '3', 'Y3_X3_BN': '64', 'Y3_X3_RSPLIT': '0', 'Y3_WGX3_WGS': '900', 'Y3_BNB_LC': '4', 'Y3_BNB_BLOCKS': '64'}) == base
     assert _run(exe, [8, 416], {'Y3_NO_FAST': '1'}) != base      # the one switch the product reads (generic kernel everywhere)
 
 
@@ -101,6 +102,12 @@ DEV_ENVS = [
     {'Y3_WGRAD_SHAPE_RULES': '0'},
     {'Y3_NO_FAST': '1'},
     {'Y3_NO_DGRAD_MULTI': '1'},
+    {'Y3_X3_WGS': '700'},
+    {'Y3_X3_WGS': '1400', 'Y3_X3_RSPLIT': '1'},
+    {'Y3_X3_KS': '3', 'Y3_X3_RSPLIT': '0'},
+    {'Y3_X3_BN': '64', 'Y3_X3_KS': '16'},
+    {'Y3_WGX3_WGS': '1500'},
+    {'Y3_WGX3_WGS': '100'},
 ]
 
 
@@ -116,17 +123,17 @@ def test_plans_match_the_product_library(sweeps):
     exe, _ = sweeps
     sys.path.insert(0, os.path.join(ROOT, 'object-detection-yolov3_amd'))
     from yolo3 import _hip
-    rows = [ln.split() for ln in _run(exe, [8, 416]).splitlines() if ln.startswith(('conv ', 'wgrad '))]
-    assert len(rows) > 200
+    rows = [ln.split() for ln in _run(exe, [8, 416]).splitlines() if ln.startswith(('conv ', 'wgrad ', 'wgrad_x3 '))]
+    assert len(rows) > 200 and any('_x3' in r[1] for r in rows if r[0] == 'conv') and any(r[0] == 'wgrad_x3' for r in rows)
     for r in rows:
         kv = dict(x.split('=') for x in r[1:] if '=' in x)
         m, cin, k, cout = (int(kv[x]) for x in ('m', 'cin', 'k', 'cout'))
         if r[0] == 'conv':
             o = (C.c_int * 13)()
-            ws = _hip.lib.y3_conv2d_plan(m, cin, k, cout, o)
+            ws = _hip.lib.y3_conv2d_plan_x(m, cin, k, cout, _hip.CONV_X3 if '_x3' in r[1] else 0, o)
             want = [int(kv[x]) for x in ('bm', 'bn', 'bk', 'tiles', 'f', 's0', 's1', 'c0', 'c1', 'grid', 'stats', 'fast', 'nk')]
         else:
             o = (C.c_int * 8)()
-            ws = _hip.lib.y3_conv2d_wgrad_plan(m, cin, k, cout, o)
+            ws = _hip.lib.y3_conv2d_wgrad_plan_x(m, cin, k, cout, _hip.CONV_X3 if r[0] == 'wgrad_x3' else 0, o)
             want = [int(kv[x]) for x in ('bkr', 'bn', 'splits', 'chunk', 'tiles', 'in_kernel', 'grid')]
         assert list(o)[:len(want)] == want and int(ws) == int(kv['ws']), r

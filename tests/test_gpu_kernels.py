@@ -530,11 +530,18 @@ def test_conv_x3_error_against_fp64_is_that_of_the_f32_instruction(hip, shape):
 WGRAD_CASES = CONV_CASES[:6] + CONV_CASES[9:10] + [(8, 52, 52, 128, 256, 1, 1), (2, 64, 64, 32, 64, 3, 2)]
 
 
-@pytest.mark.parametrize('case', WGRAD_CASES)
-def test_conv_wgrad(hip, case):
-    """y3_conv2d_wgrad vs autograd; 5e-5 * max|ref| (fp32 sums over up to 21k pixels, fp32 slab combine)."""
+@pytest.mark.parametrize('arith', ['f32', 'x3'])
+@pytest.mark.parametrize('case', WGRAD_CASES + [(8, 26, 26, 256, 512, 3, 1), (4, 52, 52, 128, 256, 3, 1), (2, 30, 26, 64, 192, 3, 2)])
+def test_conv_wgrad(hip, case, arith):
+    """y3_conv2d_wgrad vs autograd; 5e-5 * max|ref| (fp32 sums over up to 21k pixels, fp32 slab combine).  arith = 'x3':
+    y3_conv2d_wgrad_x with Y3_CONV_X3 (both operands split into three bf16 pieces, transposed LDS reads), same tolerance."""
     from util import nhwc_buf, stream, assert_close
     n, h, w, cin, cout, k, s = case
+    x3 = 0
+    if arith == 'x3':
+        if not hip.lib.y3_conv2d_wgrad_x3_ok(n * (-(-h // s)) * (-(-w // s)), cin, k, cout):
+            pytest.skip('the x3 kernel gradient does not take this shape')
+        x3 = hip.CONV_X3
     g = torch.Generator().manual_seed(13)
     x = torch.randn(n, cin, h, w, generator=g)
     wk = (torch.randn(k, k, cin, cout, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
@@ -550,10 +557,10 @@ def test_conv_wgrad(hip, case):
     ddv.copy_(dy.permute(0, 2, 3, 1))
     src = hip.Tensor(sv.data_ptr(), n, h, w, cin, cin + 4)
     dd = hip.Tensor(ddv.data_ptr(), n, oh, ow, cout, cld)
-    wsb = int(hip.lib.y3_conv2d_wgrad_workspace(src, dd, k, s))
+    wsb = int(hip.lib.y3_conv2d_wgrad_workspace_x(src, dd, k, s, x3))
     ws = torch.zeros(wsb // 4 + 4, device='cuda')        # tickets in the head: zeroed once (yolo3hip.h)
     dw = torch.full((k, k, cin, cout), float('nan'), device='cuda')
-    hip.check(hip.lib.y3_conv2d_wgrad(src, dd, k, s, dw.data_ptr(), ws.data_ptr(), wsb, stream()))
+    hip.check(hip.lib.y3_conv2d_wgrad_x(src, dd, k, s, dw.data_ptr(), x3, ws.data_ptr(), wsb, stream()))
     assert_close(dw.cpu(), wk.grad, rtol=5e-5, what='wgrad')
 
 

@@ -19,7 +19,7 @@ gts = [torch.from_numpy(x).cuda() for x in bench.synth_labels(np.random.default_
 yolo.train_step((images, gts))
 plan = yolo._plan(8, True)
 st = torch.cuda.current_stream().cuda_stream
-names = {'y3_conv2d_fwd': 'fwd', 'y3_conv2d_dgrad': 'dgrad', 'y3_conv2d_dgrad_bn': 'dgradb', 'y3_conv2d_wgrad': 'wgrad'}
+names = {'y3_conv2d_fwd': 'fwd', 'y3_conv2d_dgrad': 'dgrad', 'y3_conv2d_dgrad_bn': 'dgradb', 'y3_conv2d_wgrad': 'wgrad', 'y3_conv2d_wgrad_x': 'wgrad'}
 best = {}
 for rep in range(3):
     recs = []

@@ -18,6 +18,7 @@ ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--x3-only', action='store_true')
 ap.add_argument('--pad', type=int, default=0, help='pixel pitch of the activations = channels + pad floats')
+ap.add_argument('--wgrad', action='store_true', help='time the kernel gradient, f32 and x3')
 ap.add_argument('--stride2', action='store_true', help='time the five stride-2 forward layers instead')
 ap.add_argument('--all', action='store_true', help='every stride-1 shape of the net the x3 kernels take')
 args = ap.parse_args()
@@ -33,6 +34,41 @@ if args.all:
 lib = _hip.lib
 st = torch.cuda.current_stream().cuda_stream
 g = torch.Generator().manual_seed(0)
+
+if args.wgrad:
+    shapes = [(52, 128, 256, 3, 1), (26, 256, 512, 3, 1), (13, 512, 1024, 3, 1), (104, 64, 128, 3, 1), (104, 128, 256, 3, 2), (52, 256, 512, 3, 2), (26, 512, 1024, 3, 2),
+              (52, 256, 128, 1, 1), (26, 512, 256, 1, 1), (13, 1024, 512, 1, 1)]
+    for (hh, cin, cout, k, s_) in shapes:
+        oh = hh // s_
+        xd = torch.randn(N, hh, hh, cin, device='cuda')
+        dyd = torch.randn(N, oh, oh, cout, device='cuda')
+        X, DY = _hip.Tensor(xd.data_ptr(), N, hh, hh, cin, cin), _hip.Tensor(dyd.data_ptr(), N, oh, oh, cout, cout)
+        dws = [torch.empty(k, k, cin, cout, device='cuda') for _ in range(2)]
+        wss = []
+        for fl in (0, _hip.CONV_X3):
+            wsb = int(lib.y3_conv2d_wgrad_workspace_x(X, DY, k, s_, fl))
+            wss.append(torch.zeros(wsb // 4 + 16, device='cuda'))
+        ok = lib.y3_conv2d_wgrad_x3_ok(N * oh * oh, cin, k, cout)
+
+        def f(x3):
+            _hip.check(lib.y3_conv2d_wgrad_x(X, DY, k, s_, dws[x3].data_ptr(), _hip.CONV_X3 if x3 else 0, wss[x3].data_ptr(), wss[x3].numel() * 4, st), 'wgrad')
+        evs = []
+        for x3 in ((0, 1, 0, 1) if ok else (0, 0)):
+            for _ in range(3):
+                f(x3)
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(args.iters):
+                f(x3)
+            e.record()
+            torch.cuda.synchronize()
+            evs.append(a.elapsed_time(e) / args.iters * 1e3)
+        if ok:
+            err = float((dws[0] - dws[1]).abs().max() / dws[0].abs().max())
+            print('wgrad %4d->%4d k%d s%d @%3d: f32 %6.1f / %6.1f us   x3 %6.1f / %6.1f us   max |x3 - f32| / max|f32| %.2e' % (cin, cout, k, s_, hh, evs[0], evs[2], evs[1], evs[3], err), flush=True)
+        else:
+            print('wgrad %4d->%4d k%d s%d @%3d: f32 %6.1f / %6.1f us   (x3 does not take it)' % (cin, cout, k, s_, hh, evs[0], evs[1]), flush=True)
+    sys.exit(0)
 
 if args.stride2:
     for (hh, cin, cout) in ((416, 32, 64), (208, 64, 128), (104, 128, 256), (52, 256, 512), (26, 512, 1024)):
