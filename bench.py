@@ -275,12 +275,14 @@ def spawn_ranks(n, timeout_s=1500.0):
         err.close()
     sys.stdout.write(open(os.path.join(tmp, 'rank0.out')).read())
     sys.stdout.flush()
+    for r in range(n):      # stderr of every rank is relayed (RCCL warnings of rank > 0 would otherwise be lost): a short tail on success
+        tail = open(os.path.join(tmp, 'rank%d.err' % r)).read()[-(1500 if failed else 400):]
+        if tail.strip():
+            sys.stderr.write('--- rank %d stderr (tail) ---\n%s\n' % (r, tail))
     if failed:
-        for r in range(n):
-            tail = open(os.path.join(tmp, 'rank%d.err' % r)).read()[-1500:]
-            if tail:
-                sys.stderr.write('--- rank %d stderr (tail) ---\n%s\n' % (r, tail))
-        raise SystemExit('bench ranks failed: %s (exit codes %s)' % (failed, [p.returncode for p in procs]))
+        raise SystemExit('bench ranks failed: %s (exit codes %s); per-rank logs kept in %s' % (failed, [p.returncode for p in procs], tmp))
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -315,8 +317,9 @@ def main():
         raise SystemExit('--gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     ndev = torch.cuda.device_count()               # counting devices does not initialise the GPU
     isolated = any(os.environ.get(k) for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'))
-    if world > 1 and args.backend == 'nccl' and ndev < int(os.environ.get('LOCAL_WORLD_SIZE', str(world))) and not (isolated and ndev >= 1):
-        # (a launcher that hands every rank its own device through *_VISIBLE_DEVICES shows one device per rank: that is fine)
+    if world > 1 and args.backend == 'nccl' and ndev < int(os.environ.get('LOCAL_WORLD_SIZE', str(world))) and not (isolated and ndev == 1):
+        # (a launcher that hands every rank its OWN device through *_VISIBLE_DEVICES shows exactly one device per rank: that is fine;
+        # a mask that shows several but fewer than the ranks would put two ranks on one device)
         raise SystemExit('backend nccl (= RCCL) needs one GPU per rank: %d visible, %d ranks (use --backend gloo to rehearse on fewer GPUs)' % (ndev, world))
     torch.cuda.set_device(local_rank % max(1, ndev))
     import torch.distributed as dist
@@ -372,21 +375,31 @@ def main():
     del loss_extra
     comm = None
     if strategy is not None:
-        # one instrumented step (outside the timed region): HIP events around every bucket's all-reduce on the comm stream and
-        # around the compute stream's wait in finish_step -- how long the collectives ran, and how much of that the compute
-        # stream actually waited for (the exposed, un-overlapped part)
+        # two instrumented steps (outside the timed region).  (1) the TIMED stream topology, untouched: only a pair of events on the
+        # compute stream around finish_step's wait = the exposed, un-overlapped part of the collectives as the timed steps see it.
+        # (2) the own-stream protocol (what collect_stats switches the torch + nccl transport to): events around every bucket's
+        # all-reduce on the comm stream too -- how long the collectives themselves ran.  Both labelled with their protocol.
+        strategy.time_wait = True
+        yolo.dist_train_step(strategy, inputs)
+        barrier()
+        st_timed = strategy.step_stats() or {}
+        strategy.time_wait = False
         strategy.collect_stats = True
         yolo.dist_train_step(strategy, inputs)
         barrier()
         st_ = strategy.step_stats() or {}
         strategy.collect_stats = False
-        comm = strategy.comm_info()
+        comm = strategy.comm_info()      # backend, transport, world size, ranks_summed (ones through the gradient path), RCCL version
         comm.update(st_)
+        comm['timed_topology'] = st_timed
         comm['payload_mb_per_step'] = sum(hi - lo for lo, hi, _ in strategy.buckets) * 4 / 1e6
+        # host side per rank: launch work of one step (max over ranks below), threads torch may use, CPUs of the box
+        comm['host'] = {'torch_threads_per_rank': torch.get_num_threads(), 'cpus': os.cpu_count(), 'local_world_size': int(os.environ.get('LOCAL_WORLD_SIZE', str(world))),
+                        'reader_processes_per_rank': 0, 'note': 'bench.py feeds resident synthetic batches: no reader processes; train.py starts min(--reader_count, cpus // LOCAL_WORLD_SIZE - 1) per rank'}
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([dt, t_issued], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt, t_issued = float(tt[0].item()), float(tt[1].item())      # both: max over ranks
         if args.check_replicas:
             ref = yolo.params.clone()
             dist.broadcast(ref, src=0)

@@ -970,7 +970,7 @@ static void launch_bf16(const Bf16Args& args, int grid, hipStream_t st) {
 
 // Split-K plan of the 64 x 64-tile path (the small-M layers: 13x13 / 26x26 grids at batch 8, 19x19 at 8 x 608^2): without it a
 // workgroup walks the whole K = 9 Cin (144 steps of 32 at Cin = 512) on its own while most of the chip's wave slots idle.
-#define Y3_BF16_SK_HEADER (64 * 1024)      // tickets: 16 384 tiles
+#define Y3_BF16_SK_HEADER (256 * 1024)     // tickets: the same 256 KiB header as the fp32 entries (yolo3hip.h workspace contract), so a shared workspace has ONE layout
 struct Bf16Split {
     int splits, chunk;
     size_t ws_bytes;

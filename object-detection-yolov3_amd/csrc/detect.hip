@@ -2,6 +2,8 @@
 // analytic backward (model.py:230-354) and class-wise NMS (bbox_utils.py:200-281).
 // Compiled with -ffp-contract=off: the NMS arithmetic must round exactly like the
 // reference's NumPy float32 elementwise ops so the integer keep indices match.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define Y3_MAX_ANCHORS 16
@@ -252,6 +254,13 @@ extern "C" int y3_loss_fwd_bwd(const y3_tensor* fm, const float* gt, const float
     p.partials = (float*)workspace + Y3_MAX_ANCHORS;
     // (a kernel, not hipMemsetAsync: as a memset NODE of a captured graph the clear was not reliably ordered against the loss kernels of
     // the previous scale, which read the same flags -- a replayed training step computed a wrong loss after the GPU had idled)
+#ifdef Y3_DEV
+    // development (tools/graph_dump.py): the round-3 form again, to look at the memset NODE it becomes in a captured step
+    static const int use_memset = getenv("Y3_LOSS_MEMSET") ? atoi(getenv("Y3_LOSS_MEMSET")) : 0;
+    if (use_memset) {
+        if (hipMemsetAsync(p.present, 0, Y3_MAX_ANCHORS * sizeof(int), st) != hipSuccess) return Y3_ELAUNCH;
+    } else
+#endif
     hipLaunchKernelGGL(loss_clear_kernel, dim3(1), dim3(64), 0, st, p.present);
     Y3_CHECK_LAUNCH("loss_clear");
     const long long total = (long long)p.N * p.G_h * p.G_w * p.A;

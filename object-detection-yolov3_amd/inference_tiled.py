@@ -129,7 +129,7 @@ def finalize_predictions(boxes_list, scores_list, class_label_list, img_size):
     return np.concatenate((boxes, scores, class_label), axis=-1)
 
 
-def plan_tile_batches(n_tiles, tile_size, compute_units=256):
+def plan_tile_batches(n_tiles, tile_size, compute_units=256, mem_budget_bytes=None):
     """How many tiles go into each network launch on the bf16 conv path.  The layers that carry the FLOPs run on 256 x 256
     output tiles, one workgroup per CU (csrc/conv_bf16.hip, conv_bf16_pp_kernel), so a launch costs whole ROUNDS of 256
     workgroups: a batch of 25 tiles of 608^2 is 565 workgroups on the /8 stage -- three rounds for 2.2 rounds of work.  The
@@ -138,6 +138,17 @@ def plan_tile_batches(n_tiles, tile_size, compute_units=256):
     (remainder batch included) is taken: 45 + 45 + 10 for the 100 tiles of a 4096^2 image at 608^2 (measured network rate
     on MI355X: 3 660 tiles/s at 25, 4 520 at 44).  Returns the list of batch sizes."""
     th, tw = int(tile_size[0]), int(tile_size[1])
+    # A batch also has to FIT: the bf16 plan keeps every layer's output (about 110 bf16 values per input pixel, measured: 45 tiles
+    # of 608^2 take 3.7 GB) -- cap the batch so that it stays within a quarter of `mem_budget_bytes` (the caller passes the free
+    # device memory; None: no cap).  The round model itself only knows the 256-CU MI355X with the three-stage 11 / 11 / 7 layer
+    # weights it was measured on: for another CU count the plain BATCH_SIZE is used.
+    cap = 64
+    if mem_budget_bytes is not None:
+        per_tile = 110 * 2 * th * tw
+        cap = max(1, min(cap, int(0.25 * mem_budget_bytes // per_tile)))
+    if compute_units != 256:
+        b = max(1, min(BATCH_SIZE, cap, n_tiles))
+        return [b] * (n_tiles // b) + ([n_tiles % b] if n_tiles % b else [])
 
     def cost(b):
         c = 0
@@ -147,7 +158,7 @@ def plan_tile_batches(n_tiles, tile_size, compute_units=256):
         return c
 
     best = None
-    for b in range(4, 65):
+    for b in range(min(4, cap), cap + 1):
         full, rem = divmod(n_tiles, b)
         total = full * cost(b) + (cost(rem) if rem else 0)
         if best is None or total < best[0]:
@@ -202,7 +213,12 @@ def inference_image_tiled(yolo_model, img, tile_size, min_roi_size, batch_size=N
 
     if batch_size is None:
         bf16 = getattr(getattr(yolo_model, '_y', None), 'inference_precision', 'fp32') == 'bf16'
-        sizes = plan_tile_batches(len(xs), tile_size) if bf16 else None
+        if bf16:
+            dev = torch.cuda.current_device()
+            sizes = plan_tile_batches(len(xs), tile_size, compute_units=torch.cuda.get_device_properties(dev).multi_processor_count,
+                                      mem_budget_bytes=torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev))
+        else:
+            sizes = None
         batch_size = BATCH_SIZE
     else:
         sizes = None

@@ -100,9 +100,13 @@ def train_model(batch_size, test_every_n_steps, train_database_filepath, test_da
         if world > 1:
             os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
             if backend == 'nccl':                  # = RCCL over xGMI, one GPU per rank
+                # a launcher that hands every rank its OWN device through *_VISIBLE_DEVICES shows exactly one device per rank: fine.
+                # A mask that shows several devices but fewer than the ranks would put two nccl ranks on one device.
                 isolated = any(os.environ.get(k) for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'))
-                if torch.cuda.device_count() < int(os.environ.get('LOCAL_WORLD_SIZE', str(world))) and not isolated:
-                    raise RuntimeError('backend nccl (RCCL) needs one GPU per rank; use --backend gloo to rehearse on fewer')
+                ndev = torch.cuda.device_count()
+                if ndev < int(os.environ.get('LOCAL_WORLD_SIZE', str(world))) and not (isolated and ndev == 1):
+                    raise RuntimeError('backend nccl (RCCL) needs one GPU per rank: %d visible for %s ranks; use --backend gloo to rehearse on fewer'
+                                       % (ndev, os.environ.get('LOCAL_WORLD_SIZE', str(world))))
                 dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank % torch.cuda.device_count()))
             else:
                 dist.init_process_group(backend)

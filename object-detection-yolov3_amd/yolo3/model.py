@@ -387,12 +387,15 @@ class _Plan:
         # loss (model.py:214-354): always available (test_step needs it in inference mode too)
         self.gt = [torch.zeros(N, f.h, f.w, A, 5 + K, dtype=torch.float32, device=dev) for f in self.fms]
         self.loss4 = torch.zeros(4, dtype=torch.float32, device=dev)
-        self.loss_ws = torch.zeros(int(lib.y3_loss_workspace_bytes()) // 4 + 4, dtype=torch.float32, device=dev)
+        # one workspace PER SCALE (anchor-present flags + block partials): the three calls of a step then share no word that one
+        # clears while another has set or reads it (round 3: a shared flag array cleared by a memset node was mis-ordered in a replayed graph)
+        ws_floats = (int(lib.y3_loss_workspace_bytes()) // 4 + 4 + 63) // 64 * 64
+        self.loss_ws = torch.zeros(3 * ws_floats, dtype=torch.float32, device=dev)
         self.loss_calls = []
-        for f, g in zip(self.fms, self.gt):
+        for si, (f, g) in enumerate(zip(self.fms, self.gt)):
             f.grad = self._new(N, f.h, f.w, D, Dld, zero=True)
             self.loss_calls.append((lib.y3_loss_fwd_bwd, (f.v, g.data_ptr(), mdl.anchors_c, A, K, H, W, float(mdl.global_batch_size),
-                                                          self.loss4.data_ptr(), f.grad.v, self.loss_ws.data_ptr())))
+                                                          self.loss4.data_ptr(), f.grad.v, self.loss_ws.data_ptr() + 4 * si * ws_floats)))
             f.gw = True
         if tr:
             self._build_backward()
@@ -626,7 +629,8 @@ class _Plan:
         check(fn(*args, stream), 'y3_decode_fwd')
 
     def run_loss(self, stream):
-        self.loss4.zero_()
+        # (a kernel launch, not tensor.zero_(): inside a captured step nothing may turn into a memset node -- DESIGN 9)
+        check(lib.y3_fill(self.loss4.data_ptr(), 4, 0.0, stream), 'y3_fill')
         for fn, args in self.loss_calls:
             check(fn(*args, stream), 'y3_loss_fwd_bwd')
 

@@ -81,6 +81,7 @@ class DataParallel:
         if self.transport not in ('torch', 'native'):
             raise ValueError("transport must be 'torch' or 'native'")
         self.collect_stats = bool(collect_stats)
+        self.time_wait = False      # record events around finish_step's wait WITHOUT changing the stream protocol (the timed, "lean" topology)
         self.model = None
         self.comm = None            # HIP stream the collectives are issued on
         self._native = None         # ncclComm_t of the native transport
@@ -143,13 +144,43 @@ class DataParallel:
             info['communicator_ranks'] = int(n.value)
             info['rccl_version'] = int(ver.value)
         else:
-            info['communicator_ranks'] = dist.get_world_size(self.group)
+            info['communicator_ranks'] = dist.get_world_size(self.group)      # (the launcher's number; `ranks_summed` below is the communicator's own word)
             if self.backend == 'nccl':
                 try:
                     info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
                 except Exception as e:          # noqa: BLE001  (diagnostic field only)
                     info['rccl_version'] = 'unavailable: %s' % e
+        if self.active and self.model is not None:
+            info['ranks_summed'] = self.ranks_summed()
         return info
+
+    def ranks_summed(self):
+        """How many ranks the GRADIENT path really sums over: a one-element tensor of ones goes through exactly what a bucket goes
+        through (same transport, same stream protocol, same waits) and comes back as the number of contributors -- on every
+        transport, including the default one where the process group hides the communicator."""
+        dev = self.model.grads.device
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        if self.comm is None:
+            dist.all_reduce(ones, op=dist.ReduceOp.SUM, group=self.group)
+            return int(round(float(ones.item())))
+        own = self._native is not None or self.backend != 'nccl' or os.environ.get('Y3_DP_OWN_STREAM') == '1'
+        main = torch.cuda.current_stream(dev)
+        if not own:
+            w = dist.all_reduce(ones, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w.wait()
+        else:
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(ready)
+                w = self._allreduce(ones)
+                done = torch.cuda.Event()
+                done.record(self.comm)
+            if w is not None:
+                w.wait()
+            main.wait_event(done)
+        main.synchronize()
+        return int(round(float(ones.item())))
 
     def broadcast_parameters(self, *tensors):
         """Replicated variables start identical (MirroredStrategy semantics): rank 0's values win."""
@@ -210,7 +241,8 @@ class DataParallel:
         if not self.active:
             return
         main = torch.cuda.current_stream(self.model.grads.device) if self.comm is not None else None
-        if self.collect_stats and main is not None:
+        timed = (self.collect_stats or self.time_wait) and main is not None
+        if timed:
             before = torch.cuda.Event(enable_timing=True)
             before.record(main)
         t0 = time.perf_counter()
@@ -220,20 +252,26 @@ class DataParallel:
         self._works = []
         if main is not None and self._last is not None:
             main.wait_event(self._last)
-        if self.collect_stats and main is not None:
+        if timed:
             after = torch.cuda.Event(enable_timing=True)
             after.record(main)
             self._wait_span = (before, after)
 
     def step_stats(self):
-        """After a step run with ``collect_stats`` (and a device synchronize): durations of the collectives on the comm stream
-        and the time the compute stream sat in finish_step's wait (= the exposed, un-overlapped part)."""
-        if not self._timing:
+        """After a step (and a device synchronize).  With ``collect_stats``: durations of the collectives on this object's OWN comm
+        stream (that mode switches the torch + nccl transport from the process group's stream to the own-stream protocol, so the
+        figures are labelled ``stats_protocol: own_stream``) and the time the compute stream sat in finish_step's wait.  With
+        ``time_wait`` only: that wait alone, in the stream topology the timed steps use (``stats_protocol: timed``).
+        gloo waits on the HOST (its events bracket the enqueue only): there ``host_wait_ms`` is the figure and no event spans
+        are reported."""
+        if not self._timing and self._wait_span is None:
             return None
         torch.cuda.synchronize()
-        durs = [a.elapsed_time(b) for a, b in self._timing]
-        out = dict(allreduce_ms_sum=float(sum(durs)), allreduce_ms_per_bucket=[round(d, 4) for d in durs],
-                   host_wait_ms=self._host_wait_s * 1e3)
+        host_side = self.backend != 'nccl' and self._native is None
+        out = dict(stats_protocol='own_stream' if self.collect_stats else 'timed', host_wait_ms=self._host_wait_s * 1e3)
+        if self._timing and not host_side:
+            durs = [a.elapsed_time(b) for a, b in self._timing]
+            out.update(allreduce_ms_sum=float(sum(durs)), allreduce_ms_per_bucket=[round(d, 4) for d in durs])
         if self._wait_span is not None:
             out['allreduce_ms_exposed'] = float(self._wait_span[0].elapsed_time(self._wait_span[1]))
         self.last_stats = out

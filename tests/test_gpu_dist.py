@@ -163,7 +163,11 @@ def test_bench_self_launches_two_ranks():
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 16 and out['replicas_identical'] is True
     comm = out['comm']          # what the communicator saw and how much of the all-reduce the compute stream waited for
     assert comm['backend'] == 'gloo' and comm['world_size'] == 2 and comm['communicator_ranks'] == 2 and comm['buckets'] >= 2
-    assert comm['allreduce_ms_sum'] > 0 and comm['allreduce_ms_exposed'] >= 0
+    assert comm['ranks_summed'] == 2                     # ones through the gradient path: what the transport really summed over
+    # gloo waits on the HOST: no event spans for the collectives, the host wait is the figure; both protocols are labelled
+    assert comm['stats_protocol'] == 'own_stream' and comm['host_wait_ms'] >= 0 and comm['allreduce_ms_exposed'] >= 0
+    assert comm['timed_topology']['stats_protocol'] == 'timed' and comm['timed_topology']['allreduce_ms_exposed'] >= 0
+    assert comm['host']['torch_threads_per_rank'] >= 1 and out['host_issue_ms_one_step_empty_queue'] > 0
     assert np.isfinite(out['final_loss']) and out['value'] > 0 and out['scaling'] == 'weak'
 
 

@@ -121,17 +121,18 @@ def test_two_stream_step_equals_graph_step_at_benchmark_size():
             assert torch.equal(a.adam_m, m.adam_m) and torch.equal(a.adam_v, m.adam_v)
 
 
-def test_tiled_fp32_pipeline_against_the_oracle_chain(precision='fp32'):
+def test_tiled_fp32_pipeline_against_the_oracle_chain():
     """BASELINE.json configs[4] against the ORACLE, end to end (the 4k test below compares two HIP paths with each other): a
     1000 x 900 x 3 image, 25 tiles of 416 x 416 (96-px ghost border).  HIP: inference_image_tiled (banded upload, fused tile
     preprocessing, fp32 network, decode, NMS on the GPU, ghost-band merge).  Oracle: the host tiler (pinned by the reference's
     tiles.json) -> NumPy z-score per tile -> oracle network fp32 -> decode -> oracle NMS -> the same merge / finalize code
     (pinned by tiled_e2e.npz; inference_tiled.py:185-310).  Boxes must match at IoU >= 0.8, class for class, both ways.
-    (The bf16 conv path is not compared at the level of merged detections: run against the oracle with the same rounding points
-    (Net.bf16, precision='bf16' below) a random network gives 0.54 / 0.50 of all and 0.65 / 0.62 of the confident boxes -- the
-    distance of the bf16 kernels to their emulation equals the distance of bf16 to fp32 itself (test_bf16_inference_matches_
-    bf16_oracle), and NMS over a random network's near-tied candidates amplifies it.  Its sharp statements are
-    test_bf16_layers_teacher_forced[608-2] per layer and the yardstick test per network.)"""
+    (The bf16 conv path is NOT compared at the level of merged detections, and no code here pretends to: measured in round 3
+    against the oracle with the same rounding points (Net.bf16), a random network gave 0.54 / 0.50 of all and 0.65 / 0.62 of the
+    boxes with score >= 0.13 -- the distance of the bf16 kernels to their emulation equals the distance of bf16 to fp32 itself
+    (test_bf16_inference_matches_bf16_oracle), and greedy NMS over a random network's near-tied, overlapping candidates turns a
+    2e-2 score difference into a different survivor.  The sharp statements for config 4 are test_bf16_layers_teacher_forced[608-2]
+    per layer (half a bf16 ulp) and test_tiled_4k_bf16_against_fp32 for the pipeline.)"""
     import contextlib
     import io
     import inference_tiled
@@ -149,11 +150,9 @@ def test_tiled_fp32_pipeline_against_the_oracle_chain(precision='fp32'):
     yolo = YoloV3(len(tiles), [416, 416, 3], K, ANCHORS, seed=1)
     x = torch.from_numpy(np.stack([t.astype(np.float32).transpose(2, 0, 1) for t in tiles])).cuda()
     params = sparse_detector(yolo, imagereader.zscore_normalize_device(x), frac=0.03, min_size=min_roi)
-    yolo.inference_precision = precision
     with contextlib.redirect_stdout(io.StringIO()):
         got = inference_tiled.inference_image_tiled(yolo.get_keras_model(), img, tile, min_roi, batch_size=25)
     net = om.Net(params, 3, len(ANCHORS), K, dtype=torch.float32)
-    net.bf16 = precision == 'bf16'      # the oracle with the bf16 path's rounding points
     bl, sl, cl = [], [], []
     for t, tx, ty in zip(tiles, xs, ys):
         im = t.astype(np.float32)
@@ -175,15 +174,8 @@ def test_tiled_fp32_pipeline_against_the_oracle_chain(precision='fp32'):
     assert got.shape[1] == 6 and want.shape[1] == 6 and len(want) >= 15, (got.shape, want.shape)
     fa = matched_fraction(got[:, 0:4], got[:, 5], want[:, 0:4], want[:, 5])
     fb = matched_fraction(want[:, 0:4], want[:, 5], got[:, 0:4], got[:, 5])
-    print('tiled %s vs oracle chain: %d / %d boxes, matched %.3f / %.3f' % (precision, len(got), len(want), fa, fb))
-    if precision == 'fp32':
-        assert fa >= 0.95 and fb >= 0.95, (fa, fb)
-    else:
-        cg, cw = got[got[:, 4] >= 0.13], want[want[:, 4] >= 0.13]
-        ca = matched_fraction(cg[:, 0:4], cg[:, 5], want[:, 0:4], want[:, 5])
-        cb = matched_fraction(cw[:, 0:4], cw[:, 5], got[:, 0:4], got[:, 5])
-        print('  confident (score >= 0.13): %d / %d boxes, matched %.3f / %.3f' % (len(cg), len(cw), ca, cb))
-        assert len(cw) >= 5 and ca >= 0.9 and cb >= 0.9 and fa >= 0.7 and fb >= 0.7, (ca, cb, fa, fb)
+    print('tiled fp32 vs oracle chain: %d / %d boxes, matched %.3f / %.3f' % (len(got), len(want), fa, fb))
+    assert fa >= 0.95 and fb >= 0.95, (fa, fb)
 
 
 def test_tiled_4k_bf16_against_fp32():
