@@ -47,11 +47,24 @@ int y3_version(void);
  * exactly (8 + 8 + 8 significant bits, round to nearest), the six piece pairs that carry more than 2^-26 of a product go through
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-class results (not bit-identical to the fmaf chain; tests/test_gpu_kernels.py
  * bounds the error against fp64 by that of the fp32 instruction) at 2.67x fewer matrix-pipe cycles.  THE WEIGHT OPERAND CHANGES
- * LAYOUT with the flag: the kernel needs K contiguous per output column, so y3_conv2d_fwd takes [tap][Cout][Cin] (what
- * y3_transpose_weights writes) and y3_conv2d_dgrad* take [tap][Cin][Cout] (the Keras kernel) -- each entry point the copy the
- * OTHER one takes without the flag.  Shapes: y3_conv2d_x3_ok(); stride-2 data gradients are not built.  Everything else -- epilogue,
- * statistics, split-K workspace contract -- is unchanged; ask the *_x queries for tile counts and workspace sizes. */
+ * with the flag: the kernel needs K contiguous per output column AND the weights already split, so `wt` / `wt_t` then point at the
+ * THREE bf16 PLANES y3_x3_split_weights() makes of the copy with that layout -- y3_conv2d_fwd: of [tap][Cout][Cin] (what
+ * y3_transpose_weights writes), y3_conv2d_dgrad*: of [tap][Cin][Cout] (the Keras kernel); each entry point the copy the OTHER one
+ * takes without the flag.  (The activations are split inside the kernels.)  Shapes: y3_conv2d_x3_ok(); stride-2 data gradients are
+ * not built.  Everything else -- epilogue, statistics, split-K workspace contract -- is unchanged; ask the *_x queries for tile
+ * counts and workspace sizes.  y3_conv2d_wgrad_x takes the same flag (both its operands are activations: no planes involved). */
 #define Y3_CONV_X3 4u
+/* The weight operand of the Y3_CONV_X3 forward / data-gradient kernels.  w: a kernel with K contiguous per row, [taps][rows][k_per_row]
+ * fp32 (forward: rows = Cout, k_per_row = Cin, i.e. what y3_transpose_weights writes; data gradient: rows = Cin, k_per_row = Cout,
+ * the Keras kernel); k_per_row a multiple of 16.  planes (bf16, 3 * taps * rows * k_per_row elements, 16-byte aligned):
+ *     planes[(((tap * k_per_row/16 + c/16) * rows + row) * 3 + piece) * 16 + c % 16] = piece `piece` of w[tap][row][c],
+ * w = piece 0 + piece 1 + piece 2 exactly (each the round-to-nearest bf16 of what the earlier ones leave): the block one K step of
+ * the kernels reads -- rows x 3 pieces x 16 k -- is contiguous. */
+int y3_x3_split_weights(const float* w, void* planes, int taps, int rows, int k_per_row, y3_stream_t stream);
+/* The same for every kernel of a parameter arena in ONE launch.  table_dev: DEVICE int32 [nlayers][5] = {arena offset of the
+ * layer's kernel (floats), taps, rows, k_per_row, index of the layer's first block}, blocks of 1024 elements; total_blocks = sum over
+ * layers of ceil(taps * rows * k_per_row / 1024).  The planes of a layer are written at planes_arena + 3 * offset (bf16 elements). */
+int y3_x3_split_weights_batched(const float* arena, void* planes_arena, const int* table_dev, int nlayers, int total_blocks, y3_stream_t stream);
 
 /*
  * Tensor view: NHWC, `ld` floats between consecutive pixels.

@@ -1248,6 +1248,10 @@ static bool make_fast(const ConvArgs& a, int ntaps, int bk, FastArgs* f) {
     p.wt = a.wt;
     p.Cper = a.C;
     p.wt_bytes = (unsigned)(wtotal * 4);
+    if (a.x3) {      // three bf16 piece planes of the K-contiguous copy (y3_x3_split_weights): 6 bytes per element, same 2 GiB limit
+        if (wtotal * 6 >= 0x7fffffffLL) return false;
+        p.wt_bytes = (unsigned)(wtotal * 6);
+    }
     for (int t = 0; t < ntaps; ++t) {
         p.tap_dh[t] = dh[t];
         p.tap_dw[t] = dw[t];

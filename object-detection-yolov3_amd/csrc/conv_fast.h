@@ -17,7 +17,7 @@
 // ---------------------------------------------------------------------------
 struct FastArgs {
     const float* src;  // biased so that every tap offset is >= 0
-    const float* wt;   // [tap][C][Nout]; the x3 kernels (conv_x3.hip): the copy with K contiguous per output column, [tap][Nout][C]
+    const float* wt;   // [tap][C][Nout]; the x3 kernels (conv_x3.hip): the bf16 piece planes y3_x3_split_weights makes of the K-contiguous copy
     int Cper;          // channels per tap (K = ntaps * Cper)
     float* dst;
     const float* bias;

@@ -19,8 +19,14 @@
 //                              (global data loaded two steps earlier), four sub-steps of <= 6 vector instructions per 16 bytes
 //   LDS-only barrier           global loads stay in flight across it
 //   slots of the other groups  reads of the next step's first pieces, global loads for the step THREE ahead
-// Weights are read from the copy of the kernel whose K axis is contiguous per output column (forward: the transposed copy
-// [tap][Cout][Cin]; data gradient: the Keras copy [tap][Cin][Cout]), so both operands share one loader and one LDS image:
+// The WEIGHTS arrive already split (y3_x3_split_weights: three bf16 planes of the copy of the kernel whose K axis is contiguous
+// per output column -- forward: [tap][Cout][Cin], data gradient: [tap][Cin][Cout] -- written once per optimiser step): the probe
+// showed the loop bound by the vector ALU, not by the matrix pipe (192 k cycles per workgroup, 106 k = the MFMA time with the
+// split ablated, loads free either way), and the weight tile was 4/5 of the split work.  A weight tile is 3 x 16-byte loads
+// and 3 ds_write_b128 per thread and step; only the activations are split in the kernel.  The planes are stored TILE-WISE,
+// [tap][C / 16][row][piece][16 k]: the 128 rows x 3 pieces x 32 bytes a workgroup needs for one K step are 12 KB of consecutive
+// addresses, every 128-byte line fully used (as [piece][tap][row][C] a step touched 32 bytes of each of 384 lines, re-fetched
+// from L2 every step: 4x the bytes, and the loop ran slower than with fp32 weights split in the kernel).  Both operands share one LDS image:
 // [piece][k half][row][8 k] bf16, the 32 lanes of a fragment read (one k half, consecutive rows) cover 512 contiguous bytes.
 #include "conv_fast.h"
 
@@ -44,8 +50,9 @@ __device__ __forceinline__ void conv_x3_body(const FastArgs& p, const int braw, 
     constexpr int BK = 16, KV = 4;
     constexpr int THREADS = 64 * WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
-    constexpr int A_LOADS = BM * KV / THREADS, B_LOADS = BN * KV / THREADS;
-    static_assert((BM * KV) % THREADS == 0 && (BN * KV) % THREADS == 0 && TM % 32 == 0 && TN % 32 == 0, "tile shape");
+    constexpr int A_LOADS = BM * KV / THREADS;
+    constexpr int B_LOADS = BN * 6 / THREADS;      // weight tile: BN rows x 3 pieces x 2 k halves of 16 bytes, consecutive in memory
+    static_assert((BM * KV) % THREADS == 0 && (BN * 6) % THREADS == 0 && TM % 32 == 0 && TN % 32 == 0, "tile shape");
     // k-half planes are 64 bytes longer than their rows: LDS stores are banked by (address / 4) mod 32, and without the pad the
     // two halves a 16-lane store group writes fall on the same banks
     constexpr int AH = BM * 8 + 32, BH = BN * 8 + 32;       // u16 per k half
@@ -74,6 +81,7 @@ __device__ __forceinline__ void conv_x3_body(const FastArgs& p, const int braw, 
 
     // loop-invariant per-lane offsets: thread -> (row idx / 4, k quad idx % 4) of both operand tiles
     unsigned a_voff[A_LOADS], a_mask[A_LOADS], b_voff[B_LOADS];
+    int b_st[B_LOADS];
     const int a_kv = tid % KV;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
@@ -95,19 +103,19 @@ __device__ __forceinline__ void conv_x3_body(const FastArgs& p, const int braw, 
         a_mask[i] = msk;
     }
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-        const int n = n0 + (tid + i * THREADS) / KV;
-        b_voff[i] = n < Nout ? (unsigned)(n * p.Cper + a_kv * 4) * 4u : Y3_OOB;
+    for (int i = 0; i < B_LOADS; ++i) {      // weight tile: 16-byte chunk j of the step's block -> row j / 6, piece (j % 6) / 2, k half j % 2
+        const int j = tid + i * THREADS, row = j / 6, part = j % 6;
+        b_voff[i] = n0 + row < Nout ? (unsigned)(n0 * 96 + j * 16) : Y3_OOB;
+        b_st[i] = (part >> 1) * 2 * BH + (part & 1) * BH + row * 8;
     }
-    // LDS addresses (u16 units): this thread's 8-byte store slot of a piece plane, and its 16-byte fragment slot
+    // LDS addresses (u16 units): this thread's 8-byte store slot of an activation piece plane, and its 16-byte fragment slots
     const int a_st = (a_kv >> 1) * AH + (tid / KV) * 8 + (a_kv & 1) * 4;
-    const int b_st = (a_kv >> 1) * BH + (tid / KV) * 8 + (a_kv & 1) * 4;
     const int a_fr = lh * AH + (wm * TM + l31) * 8;
     const int b_fr = lh * BH + (wn * TN + l31) * 8;
 
     // Global -> register staging: TWO register sets (tile of K step s in set s & 1), loads issued three steps ahead
     // (conv_fast_body); dead steps at or beyond kend fetch nothing and return zeros.
-    f32x4 ra[2][A_LOADS], rb[2][B_LOADS];
+    f32x4 ra[2][A_LOADS], rb[2][B_LOADS];      // (rb: 16 bytes of bf16 each, carried as four dwords)
     struct Soff {
         int tap, cb, toff, wrow;
         unsigned dead;
@@ -132,8 +140,9 @@ __device__ __forceinline__ void conv_x3_body(const FastArgs& p, const int braw, 
             const unsigned vo = ((a_mask[e] >> o.tap) & 1u) ? a_voff[e] : Y3_OOB;
             ra[set][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, vo, (unsigned)(o.toff + o.cb * 4), 0);
         } else {
-            // the tap's block of the K-contiguous kernel copy starts at (weight tap) * C * Nout floats
-            rb[set][e - A_LOADS] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[e - A_LOADS] | o.dead, (unsigned)(o.wrow * p.Nout + o.cb) * 4u, 0);
+            // the step's block [(weight tap) * C / 16 + chunk][Nout rows][3 pieces][16 k]: 96 bytes per row
+            constexpr int eb = e - A_LOADS;
+            rb[set][eb] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[eb] | o.dead, (unsigned)(((o.wrow + o.cb) >> 4) * p.Nout) * 96u, 0);
         }
     };
     constexpr int NW = A_LOADS + B_LOADS;
@@ -147,19 +156,11 @@ __device__ __forceinline__ void conv_x3_body(const FastArgs& p, const int braw, 
     unsigned pk0 = 0, pk1 = 0;
     auto st_addr = [&](auto W, int buf, int piece) -> unsigned short* {
         constexpr int w = decltype(W)::value;
-        if constexpr (w < A_LOADS)
-            return &lds[buf * BUF + piece * 2 * AH + a_st + w * (THREADS / KV) * 8];
-        else
-            return &lds[buf * BUF + A3 + piece * 2 * BH + b_st + (w - A_LOADS) * (THREADS / KV) * 8];
+        return &lds[buf * BUF + piece * 2 * AH + a_st + w * (THREADS / KV) * 8];
     };
-    auto split_sub = [&](auto S, auto W, auto SUB, int buf) {
+    auto split_sub = [&](auto S, auto W, auto SUB, int buf) {      // activation load W (< A_LOADS), sub-step SUB
         constexpr int set = decltype(S)::value, w = decltype(W)::value, sub = decltype(SUB)::value;
-        f32x4& v = [&]() -> f32x4& {
-            if constexpr (w < A_LOADS)
-                return ra[set][w];
-            else
-                return rb[set][w - A_LOADS];
-        }();
+        f32x4& v = ra[set][w];
         if constexpr (sub == 0) {
             pk0 = x3_pk(v[0], v[1]);
             pk1 = x3_pk(v[2], v[3]);
@@ -181,11 +182,20 @@ __device__ __forceinline__ void conv_x3_body(const FastArgs& p, const int braw, 
             *reinterpret_cast<uint2*>(st_addr(W, buf, 2)) = make_uint2(x3_pk(v[0], v[1]), x3_pk(v[2], v[3]));
         }
     };
-    auto split_store_all = [&](auto S, int buf) {     // prologue: the whole tile of register set S
-        y3_for_each_ic(std::make_integer_sequence<int, NW * 4>{}, [&](auto E) {
-            constexpr int e = decltype(E)::value;
+    auto b_store = [&](auto S, auto EB, int buf) {      // weight load EB: 16 bytes straight into its (piece, k half, row) slot
+        constexpr int set = decltype(S)::value, eb = decltype(EB)::value;
+        *reinterpret_cast<f32x4*>(&lds[buf * BUF + A3 + b_st[eb]]) = rb[set][eb];
+    };
+    constexpr int NS = A_LOADS * 4 + B_LOADS;            // LDS-store events of a K step: the split sub-steps of the activations, then the weight stores
+    auto store_event = [&](auto S, auto E, int buf) {
+        constexpr int e = decltype(E)::value;
+        if constexpr (e < A_LOADS * 4)
             split_sub(S, std::integral_constant<int, e / 4>{}, std::integral_constant<int, e % 4>{}, buf);
-        });
+        else
+            b_store(S, std::integral_constant<int, e - A_LOADS * 4>{}, buf);
+    };
+    auto split_store_all = [&](auto S, int buf) {     // prologue: the whole tile of register set S
+        y3_for_each_ic(std::make_integer_sequence<int, NS>{}, [&](auto E) { store_event(S, E, buf); });
     };
 
     // fragments: [step parity][piece][block]; a step multiplies the piece pairs in the order (0,0) (0,1) (0,2) (1,0) (1,1) (2,0)
@@ -218,7 +228,6 @@ __device__ __forceinline__ void conv_x3_body(const FastArgs& p, const int braw, 
         // events in front of the barrier: reads of pieces B2 (needed by group 2), A1 (group 3), A2 (group 5), one per slot from
         // slot 0; and the NW * 4 split sub-steps, spread evenly over the SB slots
         constexpr int NR1 = NB + MB + MB;
-        constexpr int NS = NW * 4;
         // events behind it: reads of the next step's A0, B0, B1, two per slot; then the NW global loads, one per slot
         constexpr int NR2 = MB + NB + NB;
         constexpr int SP = NM - SB;
@@ -243,10 +252,7 @@ __device__ __forceinline__ void conv_x3_body(const FastArgs& p, const int braw, 
                 }
                 constexpr int s0 = m * NS / SB, s1 = (m + 1) * NS / SB;
                 if (!Y3_ABL(2))
-                    y3_for_each_ic(std::make_integer_sequence<int, s1 - s0>{}, [&](auto D) {
-                        constexpr int s = s0 + decltype(D)::value;
-                        split_sub(G{}, std::integral_constant<int, s / 4>{}, std::integral_constant<int, s % 4>{}, cur ^ 1);
-                    });
+                    y3_for_each_ic(std::make_integer_sequence<int, s1 - s0>{}, [&](auto D) { store_event(G{}, std::integral_constant<int, s0 + decltype(D)::value>{}, cur ^ 1); });
             } else {
                 constexpr int q = m - SB;
                 if constexpr (q < RS2) {
@@ -367,8 +373,8 @@ __device__ __forceinline__ void conv_x3p_body(const FastArgs& p, const int braw,
     constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
     constexpr int PR = Y3_X3P_ROWS;
     constexpr int A4 = (PR * KV + THREADS - 1) / THREADS;      // patch loads per thread and chunk
-    constexpr int B_LOADS = BN * KV / THREADS;
-    static_assert((BN * KV) % THREADS == 0 && TM % 32 == 0 && TN % 32 == 0, "tile shape");
+    constexpr int B_LOADS = BN * 6 / THREADS;      // weight tile: BN rows x 3 pieces x 2 k halves of 16 bytes, consecutive in memory
+    static_assert((BN * 6) % THREADS == 0 && TM % 32 == 0 && TN % 32 == 0, "tile shape");
     constexpr int AHP = (PR + 1) * 8 + 32;      // u16 per k half of a patch plane: PR rows, the all-zero row (index PR), 64 bytes of pad
     constexpr int AP = 6 * AHP;                 // one patch buffer: 3 pieces x 2 k halves
     constexpr int BH = BN * 8 + 32, B3 = 6 * BH;
@@ -408,10 +414,12 @@ __device__ __forceinline__ void conv_x3p_body(const FastArgs& p, const int braw,
         pa_voff[j] = ok ? (unsigned)((q + halo) * src_ld + a_kv * 4) * 4u : Y3_OOB;
     }
     unsigned b_voff[B_LOADS];
+    int b_st[B_LOADS];
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-        const int n = n0 + (tid + i * THREADS) / KV;
-        b_voff[i] = n < Nout ? (unsigned)(n * p.Cper + a_kv * 4) * 4u : Y3_OOB;
+    for (int i = 0; i < B_LOADS; ++i) {      // weight tile: 16-byte chunk j of the step's block -> row j / 6, piece (j % 6) / 2, k half j % 2
+        const int j = tid + i * THREADS, row = j / 6, part = j % 6;
+        b_voff[i] = n0 + row < Nout ? (unsigned)(n0 * 96 + j * 16) : Y3_OOB;
+        b_st[i] = (part >> 1) * 2 * BH + (part & 1) * BH + row * 8;
     }
     // per-tap scalars: row shift of the patch, and the byte offset of the tap's block of the K-contiguous kernel copy
     int s_shift[NT];
@@ -419,7 +427,7 @@ __device__ __forceinline__ void conv_x3p_body(const FastArgs& p, const int braw,
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         s_shift[t] = (p.tap_dh[t] * aW + p.tap_dw[t]) * 8;                                   // u16 units (8 per row)
-        s_wtap[t] = (unsigned)((p.tg_w0 + (t / 3) * p.tg_wy + (t % 3) * p.tg_wx) * p.Nout) * 4u;
+        s_wtap[t] = (unsigned)((p.tg_w0 + (t / 3) * p.tg_wy + (t % 3) * p.tg_wx) >> 4);      // (weight tap) * C / 16: first 16-channel block of the tap
     }
     // which taps of this lane's output pixels stay inside the image (bit t), per 32-row block
     unsigned fmask[MB];
@@ -444,7 +452,6 @@ __device__ __forceinline__ void conv_x3p_body(const FastArgs& p, const int braw,
     }
     const int zero_fr = lh * AHP + PR * 8;
     const int pa_st = (a_kv >> 1) * AHP + (tid / KV) * 8 + (a_kv & 1) * 4;
-    const int b_st = (a_kv >> 1) * BH + (tid / KV) * 8 + (a_kv & 1) * 4;
     const int b_fr = lh * BH + (wn * TN + l31) * 8;
 
     // K bookkeeping: a slice covers whole chunks; step s of the slice is (chunk c0 + s / 9, tap s % 9)
@@ -459,7 +466,7 @@ __device__ __forceinline__ void conv_x3p_body(const FastArgs& p, const int braw,
     // tap 0, is not touched before tap 3.
     f32x4 rp[A4];                                  // patch staging (one set: loaded at tap 0 of a chunk, stored over its taps 3..8)
     f32x4 rb[3][B_LOADS];
-    X3Pk pk_a = {0, 0}, pk_b = {0, 0};
+    X3Pk pk_a = {0, 0};
     auto patch_load = [&](int chunk_rel) {         // chunk c0 + chunk_rel; beyond the slice: dead (zeros)
         const bool live = chunk_rel < nchunks;
         const unsigned soff = (unsigned)((c0 + (live ? chunk_rel : 0)) * BK) * 4u;
@@ -484,12 +491,12 @@ __device__ __forceinline__ void conv_x3p_body(const FastArgs& p, const int braw,
         constexpr int set = decltype(S)::value, e = decltype(E)::value, t = decltype(T)::value;
         const bool live = step < nk;
         const int chunk = c0 + (live ? step : 0) / NT;
-        rb[set][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[e] | (live ? 0u : Y3_OOB), s_wtap[t] + (unsigned)(chunk * BK) * 4u, 0);
+        // the step's block [(weight tap) * C / 16 + chunk][Nout rows][3 pieces][16 k]: 96 bytes per row
+        rb[set][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[e] | (live ? 0u : Y3_OOB), (s_wtap[t] + (unsigned)chunk) * (unsigned)p.Nout * 96u, 0);
     };
-    auto b_sub = [&](auto S, auto E, int buf) {
-        constexpr int set = decltype(S)::value, e = decltype(E)::value, w = e / 4, sub = e % 4;
-        unsigned short* d = &lds[BOFF + buf * B3 + b_st + w * (THREADS / KV) * 8];
-        x3_split_sub<sub>(rb[set][w], pk_b, d, d + 2 * BH, d + 4 * BH);
+    auto b_sub = [&](auto S, auto E, int buf) {      // weight load E: 16 bytes straight into its (piece, k half, row) slot
+        constexpr int set = decltype(S)::value, e = decltype(E)::value;
+        *reinterpret_cast<f32x4*>(&lds[BOFF + buf * B3 + b_st[e]]) = rb[set][e];
     };
 
     y3_bf16x8 FA[2][3][MB], FB[2][3][NB];
@@ -522,7 +529,7 @@ __device__ __forceinline__ void conv_x3p_body(const FastArgs& p, const int braw,
     {
         constexpr int NMG = MB * NB, NM = 6 * NMG, SB = Y3_X3_GB * NMG, SP = NM - SB;
         constexpr int NR1 = NB + MB + MB;          // reads in front of the barrier: B2, A1, A2
-        constexpr int NSB = B_LOADS * 4;           // weight sub-steps per step
+        constexpr int NSB = B_LOADS;               // weight stores per step
         constexpr int NSA = A4 * 4;                // patch sub-steps per chunk, spread over taps TA0 .. 8
         constexpr int TA0 = 3;
         constexpr int SA_PER = (NSA + NT - TA0 - 1) / (NT - TA0);
@@ -976,6 +983,65 @@ bool y3_wgrad_x3_launch(const WgradArgs& p, int bkr, int bn, unsigned grid, hipS
     if (bkr != 128 || bn != 128) return false;
     hipLaunchKernelGGL((conv_wgrad_x3_kernel<128, 128, 2, 2>), dim3(grid), dim3(256), 0, st, p);
     return true;
+}
+
+// ---------------------------------------------------------------------------
+// Weight planes for the kernels above.  Input: a kernel with K contiguous per row, w[tap][row][C] fp32 (forward: row = output
+// channel, C = Cin -- the transposed copy; data gradient: row = input channel, C = Cout -- the Keras copy).  Output, bf16:
+//     planes[(((tap * C/16 + c/16) * rows + row) * 3 + piece) * 16 + c % 16] = piece `piece` of w[tap][row][c]
+// (x = x0 + x1 + x2 exactly, each piece the round-to-nearest bf16 of what the earlier ones leave): the rows x 3 x 16 block one K
+// step reads is contiguous.  HBM-bound pass, once per optimiser step over both copies (batched: every layer in one launch).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void x3_split_store(const float* __restrict__ w, unsigned short* __restrict__ planes, long long e, int rows, int C) {
+    // e: flat index of 4 consecutive c of one (tap, row)
+    const long long tr = e / C;                 // tap * rows + row
+    const int c = (int)(e - tr * C);
+    const long long tap = tr / rows;
+    const int row = (int)(tr - tap * rows);
+    f32x4 r = *reinterpret_cast<const f32x4*>(w + e);
+    const unsigned a0 = x3_pk(r[0], r[1]), a1 = x3_pk(r[2], r[3]);
+    r[0] -= x3_lo(a0); r[1] -= x3_hi(a0); r[2] -= x3_lo(a1); r[3] -= x3_hi(a1);
+    const unsigned b0 = x3_pk(r[0], r[1]), b1 = x3_pk(r[2], r[3]);
+    r[0] -= x3_lo(b0); r[1] -= x3_hi(b0); r[2] -= x3_lo(b1); r[3] -= x3_hi(b1);
+    unsigned short* d = planes + (((tap * (C >> 4) + (c >> 4)) * rows + row) * 3) * 16 + (c & 15);
+    *reinterpret_cast<uint2*>(d) = make_uint2(a0, a1);
+    *reinterpret_cast<uint2*>(d + 16) = make_uint2(b0, b1);
+    *reinterpret_cast<uint2*>(d + 32) = make_uint2(x3_pk(r[0], r[1]), x3_pk(r[2], r[3]));
+}
+__global__ __launch_bounds__(256) void x3_split_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes, long long count, int rows, int C) {
+    const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e < count) x3_split_store(w, planes, e, rows, C);
+}
+// table[l] = {arena offset of the layer's kernel (floats), taps, rows, C, first block}; the layer's planes start at 3 * offset (bf16 elements)
+__global__ __launch_bounds__(256) void x3_split_weights_batched_kernel(const float* __restrict__ arena, unsigned short* __restrict__ planes_arena,
+                                                                       const int* __restrict__ table, int nlayers) {
+    int lo = 0, hi = nlayers - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 5 + 4] <= (int)blockIdx.x)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const long long off = table[lo * 5];
+    const int taps = table[lo * 5 + 1], rows = table[lo * 5 + 2], C = table[lo * 5 + 3];
+    const long long count = (long long)taps * rows * C;
+    const long long e = ((long long)((int)blockIdx.x - table[lo * 5 + 4]) * 256 + threadIdx.x) * 4;
+    if (e < count) x3_split_store(arena + off, planes_arena + 3 * off, e, rows, C);
+}
+extern "C" int y3_x3_split_weights(const float* w, void* planes, int taps, int rows, int k_per_row, y3_stream_t stream) {
+    Y3_CHECK_ARG(w && planes && taps > 0 && rows > 0 && k_per_row > 0 && k_per_row % 16 == 0, "x3_split_weights: null pointer, or K per row (%d) not a multiple of 16", k_per_row);
+    Y3_CHECK_ARG((((uintptr_t)w) & 15) == 0 && (((uintptr_t)planes) & 15) == 0, "x3_split_weights: w and planes must be 16-byte aligned");
+    const long long count = (long long)taps * rows * k_per_row;
+    hipLaunchKernelGGL(x3_split_weights_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)planes, count, rows, k_per_row);
+    Y3_CHECK_LAUNCH("x3_split_weights");
+    return Y3_OK;
+}
+extern "C" int y3_x3_split_weights_batched(const float* arena, void* planes_arena, const int* table_dev, int nlayers, int total_blocks, y3_stream_t stream) {
+    Y3_CHECK_ARG(arena && planes_arena && table_dev && nlayers > 0 && total_blocks > 0, "x3_split_weights_batched: bad args");
+    hipLaunchKernelGGL(x3_split_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, arena, (unsigned short*)planes_arena, table_dev, nlayers);
+    Y3_CHECK_LAUNCH("x3_split_weights_batched");
+    return Y3_OK;
 }
 
 // Tiles this file is built for (conv.hip plans with them): false if (bm, bn) is not one of them.

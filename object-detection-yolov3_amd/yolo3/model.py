@@ -280,7 +280,7 @@ class _Plan:
             # fp32 arithmetic as three bf16 pieces per operand (conv_x3.hip) for the layers the model's policy names: the kernel then
             # wants the copy of the weights with K contiguous per output column, i.e. the TRANSPOSED arena in the forward pass
             x3 = CONV_X3 if (not bf and mdl.x3_forward(sp, N * oh * ow)) else 0
-            wfwd = (mdl.params_t.data_ptr() + 4 * sp.w_off) if x3 else ptr(sp.w_off)
+            wfwd = (mdl.planes_t.data_ptr() + 2 * 3 * sp.w_off) if x3 else ptr(sp.w_off)      # x3: the three bf16 planes of the transposed kernel
             fneed = int(lib.y3_conv2d_fwd_workspace_x(N * oh * ow, sp.cin_pad, sp.k, sp.cout, x3))
             if x3:
                 self.x3_fwd.append(i)
@@ -570,7 +570,7 @@ class _Plan:
                     ds = self._grad_of(src)
                     # x3 data gradient: the kernel wants K (= this layer's output channels) contiguous per column: the Keras arena
                     x3 = CONV_X3 if mdl.x3_dgrad(sp, ds.m) else 0
-                    wdg = (mdl.params.data_ptr() if x3 else Wt.data_ptr()) + 4 * sp.w_off
+                    wdg = (mdl.planes.data_ptr() + 2 * 3 * sp.w_off) if x3 else (Wt.data_ptr() + 4 * sp.w_off)      # x3: planes of the Keras kernel
                     dflags = (EPI_ACCUM if src.gw else 0) | x3
                     dneed = int(lib.y3_conv2d_dgrad_workspace_x(dz.v, sp.k, sp.s, ds.v, x3))
                     if x3:
@@ -719,6 +719,13 @@ class YoloV3:
         if conv_arithmetic not in ('f32', 'x3', 'x3-all'):
             raise ValueError("conv_arithmetic must be 'f32' or 'x3'")
         self.conv_arithmetic = conv_arithmetic
+        # the x3 kernels read their weights as three bf16 piece planes (y3_x3_split_weights) of the copy with K contiguous per output
+        # column: of params_t in the forward pass, of params in the data gradient; refreshed with params_t after every optimiser step
+        self.planes = self.planes_t = None
+        if conv_arithmetic != 'f32':
+            self.planes = torch.zeros(3 * self.arena_floats, dtype=torch.bfloat16, device=dev)
+            self.planes_t = torch.zeros(3 * self.arena_floats, dtype=torch.bfloat16, device=dev)
+        self._x3_table = None
         self.params_t_bf16 = None                 # bf16 copy of params_t, made on first bf16 predict
         self._bf16_stale = True
         self.dist = None                          # set by parallel.DataParallel.attach()
@@ -880,6 +887,22 @@ class YoloV3:
             self._tr_tiles = start
         check(lib.y3_transpose_weights_batched(self.params.data_ptr(), self.params_t.data_ptr(), self._tr_table.data_ptr(), len(self.specs) - 1,
                                                self._tr_tiles, self._stream()), 'y3_transpose_weights_batched')
+        if self.planes is not None:
+            if self._x3_table is None:
+                # the layers whose channel counts the x3 kernels take (K per row a multiple of 16), per copy: {offset, taps, rows, K per row, first block}
+                tabs = []
+                for fwd_copy in (False, True):
+                    rows, start = [], 0
+                    for sp in self.specs[1:]:
+                        nrows, kpr = (sp.cout, sp.cin_pad) if fwd_copy else (sp.cin_pad, sp.cout)      # params_t: [tap][Cout][Cin]; params: [tap][Cin][Cout]
+                        if kpr % 16:
+                            continue
+                        rows.append([sp.w_off, sp.k * sp.k, nrows, kpr, start])
+                        start += -(-(sp.k * sp.k * nrows * kpr) // 1024)
+                    tabs.append((torch.tensor(rows, dtype=torch.int32, device=self.device), len(rows), start))
+                self._x3_table = tabs
+            for (arena, planes), (tab, nl, blocks) in zip(((self.params, self.planes), (self.params_t, self.planes_t)), self._x3_table):
+                check(lib.y3_x3_split_weights_batched(arena.data_ptr(), planes.data_ptr(), tab.data_ptr(), nl, blocks, self._stream()), 'y3_x3_split_weights_batched')
         self._bf16_stale = True
 
     def fold_table(self):

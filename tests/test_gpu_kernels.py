@@ -63,7 +63,7 @@ def _x3_or_skip(hip, arith, m, c, taps, nout):
 def test_conv_fwd(hip, case, arith):
     """y3_conv2d_fwd vs fp64 conv2d; tolerance 2e-5 * max|ref| (fp32 fmaf chain over K <= 1152).  arith = 'x3': the same
     call with Y3_CONV_X3 (three bf16 pieces per operand, weights in the transposed layout), same tolerance."""
-    from util import nhwc_buf, stream, assert_close
+    from util import nhwc_buf, stream, assert_close, x3_planes
     n, h, w, cin, cout, k, s = case
     x3 = _x3_or_skip(hip, arith, n * (-(-h // s)) * (-(-w // s)), cin, k * k, cout)
     g = torch.Generator().manual_seed(hash(case) % 1000)
@@ -77,7 +77,9 @@ def test_conv_fwd(hip, case, arith):
     sv.copy_(x.permute(0, 2, 3, 1))
     old = (cout + 3) // 4 * 4 + 4
     dbuf, dv = nhwc_buf(n, oh, ow, cout, ld=old)
-    wd, bd = (wk.permute(0, 1, 3, 2) if x3 else wk).contiguous().cuda(), b.cuda()      # x3: [kh,kw,co,ci]
+    wd, bd = wk.contiguous().cuda(), b.cuda()
+    if x3:
+        wd = x3_planes(hip, wk.permute(0, 1, 3, 2).contiguous().cuda())      # x3: the three bf16 planes of [kh,kw,co,ci]
     src = hip.Tensor(sv.data_ptr(), n, h, w, cin, cin + 8)
     dst = hip.Tensor(dv.data_ptr(), n, oh, ow, cout, old)
     tiles = hip.lib.y3_conv2d_stats_tiles_x(n * oh * ow, cin, k, cout, x3)
@@ -100,7 +102,7 @@ def test_conv_fwd(hip, case, arith):
 @pytest.mark.parametrize('shape', [(2, 26, 26, 64, 128, 3, 1), (1, 13, 13, 512, 1024, 3, 1), (1, 13, 13, 1024, 512, 1, 1), (1, 26, 26, 1024, 256, 1, 1)])
 def test_conv_fwd_fused_inference_epilogue(hip, shape, arith):
     """lrelu -> scale/shift -> + resid (inference-mode BN folded, model.py:38,47); the small-M shapes take the split-K path."""
-    from util import nhwc_buf, stream, assert_close
+    from util import nhwc_buf, stream, assert_close, x3_planes
     n, h, w, cin, cout, k, s = shape
     x3 = _x3_or_skip(hip, arith, n * h * w, cin, k * k, cout)
     g = torch.Generator().manual_seed(5)
@@ -115,7 +117,9 @@ def test_conv_fwd_fused_inference_epilogue(hip, shape, arith):
     _, rv = nhwc_buf(n, h, w, cout, ld=2 * cout, off=cout)
     rv.copy_(r.permute(0, 2, 3, 1))
     _, dv = nhwc_buf(n, h, w, cout)
-    wd, bd, scd, shd = (wk.permute(0, 1, 3, 2) if x3 else wk).contiguous().cuda(), b.cuda(), sc.cuda(), sh.cuda()
+    wd, bd, scd, shd = wk.contiguous().cuda(), b.cuda(), sc.cuda(), sh.cuda()
+    if x3:
+        wd = x3_planes(hip, wk.permute(0, 1, 3, 2).contiguous().cuda())
     wsb = int(hip.lib.y3_conv2d_fwd_workspace_x(n * h * w, cin, k, cout, x3))
     ws = torch.zeros(wsb // 4 + 4, device='cuda')        # tickets in the head: zeroed once (yolo3hip.h)
     hip.check(hip.lib.y3_conv2d_fwd(hip.Tensor(sv.data_ptr(), n, h, w, cin, cin), wd.data_ptr(), bd.data_ptr(), k, s,
@@ -368,7 +372,9 @@ def test_conv_dgrad(hip, case, accum, arith):
     DD, DS = hip.Tensor(ddv.data_ptr(), n, oh, ow, cout, cld), hip.Tensor(dsv.data_ptr(), n, h, w, cin, cin + 4)
     wsb = int(hip.lib.y3_conv2d_dgrad_workspace_x(DD, k, s, DS, x3))
     ws = torch.zeros(wsb // 4 + 4, device='cuda')        # tickets in the head: zeroed once (yolo3hip.h)
-    hip.check(hip.lib.y3_conv2d_dgrad(DD, (wd if x3 else wt2).data_ptr(), k, s, DS, (hip.EPI_ACCUM if accum else 0) | x3, ws.data_ptr(), wsb, stream()))
+    from util import x3_planes
+    wop = x3_planes(hip, wd) if x3 else wt2              # x3: the planes of the Keras layout
+    hip.check(hip.lib.y3_conv2d_dgrad(DD, wop.data_ptr(), k, s, DS, (hip.EPI_ACCUM if accum else 0) | x3, ws.data_ptr(), wsb, stream()))
     ref = x.grad.permute(0, 2, 3, 1)
     if accum:
         ref = ref + init.double()
@@ -403,7 +409,10 @@ def test_conv_dgrad_bn_epilogue_stats(hip, shape, accum, arith):
     ddv.copy_(dy)
     _, av = nhwc_buf(n, h, w, cin, ld=cin + 8)
     av.copy_(a)
-    wt = (wk if x3 else wk.permute(0, 1, 3, 2)).contiguous().cuda()      # x3: the Keras layout, K (= cout) contiguous per column
+    wt = (wk if x3 else wk.permute(0, 1, 3, 2)).contiguous().cuda()      # x3: the Keras layout, K (= cout) contiguous per column ...
+    if x3:
+        from util import x3_planes
+        wt = x3_planes(hip, wt)                                           # ... as three bf16 planes
     DD, A = hip.Tensor(ddv.data_ptr(), n, oh, ow, cout, cout), hip.Tensor(av.data_ptr(), n, h, w, cin, cin + 8)
     outs = []
     for fused in (False, True):
@@ -480,6 +489,10 @@ def test_conv_x3_error_against_fp64_is_that_of_the_f32_instruction(hip, shape):
     _, dyv = nhwc_buf(n, oh, oh, cout, ld=cld)
     dyv.copy_(dy.permute(0, 2, 3, 1))
     w_keras, w_t = wk.contiguous().cuda(), wk.permute(0, 1, 3, 2).contiguous().cuda()
+    from util import x3_planes
+    # (planes exist only for K per row a multiple of 16: the shapes x3 refuses get the fp32 tensor, which the call must reject before reading it)
+    p_keras = x3_planes(hip, w_keras) if cout % 16 == 0 else w_keras
+    p_t = x3_planes(hip, w_t) if cin % 16 == 0 else w_t
     X, DY = hip.Tensor(xv.data_ptr(), n, hw, hw, cin, cin), hip.Tensor(dyv.data_ptr(), n, oh, oh, cout, cld)
     m = n * oh * oh
     ok = bool(hip.lib.y3_conv2d_x3_ok(m, cin, k * k, cout))
@@ -488,7 +501,7 @@ def test_conv_x3_error_against_fp64_is_that_of_the_f32_instruction(hip, shape):
     xr = x.double().requires_grad_(True)
     ref = _conv_ref(xr, wk, None, k, s)
     outs = {}
-    for name, flag, wt in (('f32', 0, w_keras), ('x3', hip.CONV_X3, w_t)):
+    for name, flag, wt in (('f32', 0, w_keras), ('x3', hip.CONV_X3, p_t)):
         _, yv = nhwc_buf(n, oh, oh, cout, ld=cld)
         wsb = int(hip.lib.y3_conv2d_fwd_workspace_x(m, cin, k, cout, flag))
         ws = torch.zeros(wsb // 4 + 4, device='cuda')
@@ -510,7 +523,7 @@ def test_conv_x3_error_against_fp64_is_that_of_the_f32_instruction(hip, shape):
     refd = xr.grad.permute(0, 2, 3, 1)
     okd = bool(hip.lib.y3_conv2d_x3_ok(n * hw * hw, cout, k * k, cin)) and s == 1
     outs = {}
-    for name, flag, wt in (('f32', 0, w_t), ('x3', hip.CONV_X3, w_keras)):
+    for name, flag, wt in (('f32', 0, w_t), ('x3', hip.CONV_X3, p_keras)):
         _, dxv = nhwc_buf(n, hw, hw, cin, fill=0.0)
         DX = hip.Tensor(dxv.data_ptr(), n, hw, hw, cin, cin)
         wsb = int(hip.lib.y3_conv2d_dgrad_workspace_x(DY, k, s, DX, flag))

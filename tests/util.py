@@ -32,3 +32,13 @@ def assert_close(got, want, rtol=1e-4, atol=None, what=''):
     err = np.abs(got - want)
     assert np.isfinite(got).all(), '%s: non-finite output' % what
     assert err.max() <= atol, '%s: max abs err %.3e > %.3e (scale %.3e)' % (what, err.max(), atol, scale)
+
+
+def x3_planes(hip, w):
+    """The weight operand of a Y3_CONV_X3 launch: the bf16 piece planes (y3_x3_split_weights) of a CUDA fp32 kernel [kh, kw, rows, K]
+    that already has the layout the entry point wants (K contiguous per row)."""
+    w = w.contiguous()
+    kh, kw, rows, kpr = w.shape
+    planes = torch.empty(3 * w.numel(), dtype=torch.bfloat16, device=w.device)
+    hip.check(hip.lib.y3_x3_split_weights(w.data_ptr(), planes.data_ptr(), kh * kw, rows, kpr, stream()), 'y3_x3_split_weights')
+    return planes

@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
     void* dws;
     unsigned long long* dt;
     const size_t wsb = y3_conv2d_fwd_workspace_x(n * h * w, cin, k, cout, x3) + 16;
-    hipMalloc(&dx, xs * 4); hipMalloc(&dw, ws * 4); hipMalloc(&dy, ys * 4); hipMalloc(&db, cout * 4);
+    hipMalloc(&dx, xs * 4); hipMalloc(&dw, ws * 8);      /* (x3: three bf16 planes = 6 bytes per element) */ hipMalloc(&dy, ys * 4); hipMalloc(&db, cout * 4);
     hipMalloc(&dstats, (size_t)n * h * w / 16 * cout * 4 + 65536); hipMalloc(&dws, wsb);
     hipMemset(dws, 0, wsb);
     hipMemcpy(dx, hx.data(), xs * 4, hipMemcpyHostToDevice);

@@ -35,6 +35,14 @@ lib = _hip.lib
 st = torch.cuda.current_stream().cuda_stream
 g = torch.Generator().manual_seed(0)
 
+
+def planes(w):
+    """three bf16 piece planes of a CUDA fp32 tensor (the weight operand of a Y3_CONV_X3 forward / data-gradient launch)"""
+    w = w.contiguous()                                   # [kh, kw, rows, K per row]
+    out = torch.empty(3 * w.numel(), dtype=torch.bfloat16, device=w.device)
+    _hip.check(lib.y3_x3_split_weights(w.data_ptr(), out.data_ptr(), w.shape[0] * w.shape[1], w.shape[2], w.shape[3], st), 'split')
+    return out
+
 if args.wgrad:
     shapes = [(52, 128, 256, 3, 1), (26, 256, 512, 3, 1), (13, 512, 1024, 3, 1), (104, 64, 128, 3, 1), (104, 128, 256, 3, 2), (52, 256, 512, 3, 2), (26, 512, 1024, 3, 2),
               (52, 256, 128, 1, 1), (26, 512, 256, 1, 1), (13, 1024, 512, 1, 1)]
@@ -75,7 +83,7 @@ if args.stride2:
         oh = hh // 2
         xd = torch.randn(N, hh, hh, cin, device='cuda')
         wd = torch.randn(3, 3, cin, cout, device='cuda') * 0.05
-        wtd = wd.permute(0, 1, 3, 2).contiguous()
+        wtd = planes(wd.permute(0, 1, 3, 2))
         b = torch.zeros(cout, device='cuda')
         yo = torch.empty(N, oh, oh, cout, device='cuda')
         X, Y = _hip.Tensor(xd.data_ptr(), N, hh, hh, cin, cin), _hip.Tensor(yo.data_ptr(), N, oh, oh, cout, cout)
@@ -134,6 +142,7 @@ for (n, h, w, cin, cout, k) in SHAPES:
     dyd[..., :cout] = dy.permute(0, 2, 3, 1).cuda()
     wd = wk.contiguous().cuda()                                   # [tap][cin][cout]
     wtd = wk.permute(0, 1, 3, 2).contiguous().cuda()              # [tap][cout][cin]
+    pl_fwd, pl_dg = planes(wtd), planes(wd)
     b = torch.zeros(cout, device='cuda')
     yo = [torch.empty(n, h, w, cout + PAD, device='cuda') for _ in range(2)]
     dxo = [torch.empty(n, h, w, cin + PAD, device='cuda') for _ in range(2)]
@@ -145,12 +154,12 @@ for (n, h, w, cin, cout, k) in SHAPES:
 
     def fwd(x3):
         Y = _hip.Tensor(yo[x3].data_ptr(), n, h, w, cout, cout + PAD)
-        _hip.check(lib.y3_conv2d_fwd(X, (wtd if x3 else wd).data_ptr(), b.data_ptr(), k, 1, Y, _hip.EPI_LRELU | (_hip.CONV_X3 if x3 else 0), 0.2,
+        _hip.check(lib.y3_conv2d_fwd(X, (pl_fwd if x3 else wd).data_ptr(), b.data_ptr(), k, 1, Y, _hip.EPI_LRELU | (_hip.CONV_X3 if x3 else 0), 0.2,
                                      None, None, None, None, ws.data_ptr(), wsb, st), 'fwd')
 
     def dgrad(x3):
         DX = _hip.Tensor(dxo[x3].data_ptr(), n, h, w, cin, cin + PAD)
-        _hip.check(lib.y3_conv2d_dgrad(DY, (wd if x3 else wtd).data_ptr(), k, 1, DX, _hip.CONV_X3 if x3 else 0, ws.data_ptr(), wsb, st), 'dgrad')
+        _hip.check(lib.y3_conv2d_dgrad(DY, (pl_dg if x3 else wtd).data_ptr(), k, 1, DX, _hip.CONV_X3 if x3 else 0, ws.data_ptr(), wsb, st), 'dgrad')
 
     ok_f = lib.y3_conv2d_x3_ok(m, cin, taps, cout)
     ok_d = lib.y3_conv2d_x3_ok(m, cout, taps, cin)
