@@ -1027,40 +1027,20 @@ static ConvPlan plan_conv_x3(int M, int Nout, int K, int ntaps) {
     pl.tiles = pl.f = tiles;
     pl.s0 = pl.s1 = 1;
     pl.chunk0 = pl.chunk1 = even_steps(nk);
-    // measured (tools/probe/x3_sweep5.sh, batch 8 at 416^2): two workgroups of the patch kernel share a CU (75 KB of LDS each), so a
-    // launch wants at most 512 pieces; ~350 (1.4 per CU) beat ~700 (a second, mostly idle round) on every 3x3 shape but the
-    // data gradients with fewer than 64 tiles, whose slices are 72+ steps long either way
-    static const int want_env = env_int("Y3_X3_WGS", 0);
-    const int want = want_env > 0 ? want_env : (y3_cdiv(M, 128) * y3_cdiv(Nout, Nout <= 64 ? 64 : 128) < 64 ? 700 : 350);
     static const int min_steps = env_int("Y3_X3_MINSTEPS", 12);
     // slices are whole units of K steps: 3x3 launches in units of 18 (two 16-channel chunks of nine taps: the patch kernel's loop
     // body, conv_x3.hip), the others in pairs of steps
     const int unit = ntaps == 9 ? 18 : 2;
     static const int rsplit_on = env_int("Y3_X3_RSPLIT", 2);      // 0 off, 1 only where the uniform split does not apply, 2 preferred above 256 tiles
-    if (tiles <= Y3_MAX_TICKETS && tiles * 4 <= want * 3 && !(rsplit_on == 2 && tiles > 256)) {
-        int ks = (want + tiles / 2) / tiles;
-        if (ks > nk / min_steps) ks = nk / min_steps;
-        if (ks > 16) ks = 16;
-        {
-            static const int force_ks = env_int("Y3_X3_KS", 0);      // development: this many K slices for every split launch
-            if (force_ks > 0) ks = force_ks;
-        }
-        if (ks > 1) {
-            pl.chunk0 = y3_cdiv(y3_cdiv(nk, ks), unit) * unit;
-            pl.s0 = y3_cdiv(nk, pl.chunk0);
-            if (pl.s0 <= 1) {
-                pl.s0 = 1;
-                pl.chunk0 = even_steps(nk);
-            }
-        }
-    }
-    else if (tiles <= Y3_MAX_TICKETS && tiles > 256) {
+    static const int force_ks = env_int("Y3_X3_KS", 0);           // development: this many K slices for every split launch
+    static const int slots = env_int("Y3_X3_SLOTS", 512);         // two workgroups of the patch kernel per CU
+    if (tiles <= Y3_MAX_TICKETS && tiles > 256 && rsplit_on && !force_ks) {
         // more tiles than CUs but too few to balance by themselves (338 tiles: a third of the CUs would carry two): whole rounds of
         // tiles stay whole -- no slabs for them -- and only the remainder round is cut, so that its pieces spread evenly
         const int F = tiles / 256 * 256, R = tiles - F;
         int best = 1;
         double best_cost = 1.0;
-        for (int S = 2; rsplit_on && S <= 6; ++S) {
+        for (int S = 2; S <= 6; ++S) {
             const int ch = y3_cdiv(y3_cdiv(nk, S), unit) * unit;
             if (ch * S != nk || ch < min_steps) continue;             // equal slices only
             const double cost = (double)y3_cdiv((long long)R * S, 256) / S + 0.03 * (S - 1);
@@ -1074,9 +1054,40 @@ static ConvPlan plan_conv_x3(int M, int Nout, int K, int ntaps) {
             pl.chunk1 = nk / best;
             pl.s1 = best;
         }
+    } else if (tiles <= Y3_MAX_TICKETS && tiles <= 256) {
+        // Fewer tiles than CUs: cut along K so that the launch fills the chip's workgroup slots ONCE, two per CU -- a lone workgroup
+        // (one wave per SIMD) runs its loop at a third of the MFMA rate, and a second, partly filled round costs a whole round
+        // (measured, tools/probe/x3_sweep5/9.sh: 507 pieces 78 us, 338 pieces 97 us, 676 pieces 103 us on the same launch).
+        // The slice counts a launch can have are ceil(nk / c) for c a multiple of the unit; take the largest count s_lo with
+        // tiles * s_lo <= slots and give the next larger one, s_hi, to as many tiles as fill the rest of the slots.
+        auto count_for = [&](int c) { return y3_cdiv(nk, c); };
+        int c_lo = 0, c_hi = 0;      // chunk lengths of the counts s_lo <= slots / tiles < s_hi
+        for (int c = y3_cdiv(nk, unit) * unit; c >= unit && c >= min_steps; c -= unit) {      // slice counts grow as c shrinks
+            const int sc = count_for(c);
+            if (sc > 16) break;
+            const bool fits = force_ks ? sc <= force_ks : (long long)tiles * sc <= slots;
+            if (fits)
+                c_lo = c;
+            else if (c_hi == 0 && !force_ks && (c_lo == 0 || sc > count_for(c_lo)))
+                c_hi = c;
+        }
+        const int s_lo = c_lo > 0 ? count_for(c_lo) : 1;
+        if (s_lo > 1) {
+            pl.s0 = pl.s1 = s_lo;
+            pl.chunk0 = pl.chunk1 = c_lo;
+        }
+        if (c_hi > 0) {      // tiles [0, f) take the next larger count: f * s_hi + (tiles - f) * s_lo <= slots
+            const int s_hi = count_for(c_hi);
+            const int f = (int)((slots - (long long)tiles * s_lo) / (s_hi - s_lo));
+            if (f > 0) {
+                pl.f = f < tiles ? f : tiles;
+                pl.s0 = s_hi;
+                pl.chunk0 = c_hi;
+            }
+        }
     }
     pl.stats_tiles = y3_cdiv(M, pl.t.bm);
-    const long long split_items = pl.s0 > 1 ? (long long)tiles * pl.s0 : (pl.s1 > 1 ? (long long)(tiles - pl.f) * pl.s1 : 0);
+    const long long split_items = pl.s0 > 1 ? (long long)pl.f * pl.s0 + (long long)(tiles - pl.f) * pl.s1 : (pl.s1 > 1 ? (long long)(tiles - pl.f) * pl.s1 : 0);
     const long long slab_bytes = split_items * pl.t.bm * pl.t.bn * 4;
     if (slab_bytes >= 0x7ff00000LL) {
         pl.f = tiles;
@@ -1251,6 +1262,8 @@ static bool make_fast(const ConvArgs& a, int ntaps, int bk, FastArgs* f) {
     if (a.x3) {      // three bf16 piece planes of the K-contiguous copy (y3_x3_split_weights): 6 bytes per element, same 2 GiB limit
         if (wtotal * 6 >= 0x7fffffffLL) return false;
         p.wt_bytes = (unsigned)(wtotal * 6);
+        static const int mode = env_int("Y3_X3_MODE", 1);
+        p.x3_mode = mode;
     }
     for (int t = 0; t < ntaps; ++t) {
         p.tap_dh[t] = dh[t];

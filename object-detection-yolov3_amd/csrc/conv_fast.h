@@ -19,6 +19,7 @@ struct FastArgs {
     const float* src;  // biased so that every tap offset is >= 0
     const float* wt;   // [tap][C][Nout]; the x3 kernels (conv_x3.hip): the bf16 piece planes y3_x3_split_weights makes of the K-contiguous copy
     int Cper;          // channels per tap (K = ntaps * Cper)
+    int x3_mode;       // x3 kernels: bit 0 = non-temporal activation loads
     float* dst;
     const float* bias;
     const float* scale;

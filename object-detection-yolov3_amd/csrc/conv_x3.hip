@@ -464,6 +464,9 @@ __device__ __forceinline__ void conv_x3p_body(const FastArgs& p, const int braw,
     // workgroup against 56 k with the loads ablated).  The weight tiles therefore go through a ring of THREE sets (tile s in set
     // s % 3, loaded in step s - 4, stored in step s - 1: two full steps in flight), and the patch of the next chunk, loaded at
     // tap 0, is not touched before tap 3.
+    // The activations stream through an XCD's L2 once per launch (each patch row is read by one workgroup of the XCD), the weight
+    // block of the XCD's column tiles is re-read by every row tile: the patch loads are non-temporal so that they do not evict it.
+    const bool a_nt = (p.x3_mode & 1) != 0;
     f32x4 rp[A4];                                  // patch staging (one set: loaded at tap 0 of a chunk, stored over its taps 3..8)
     f32x4 rb[3][B_LOADS];
     X3Pk pk_a = {0, 0};
@@ -471,13 +474,16 @@ __device__ __forceinline__ void conv_x3p_body(const FastArgs& p, const int braw,
         const bool live = chunk_rel < nchunks;
         const unsigned soff = (unsigned)((c0 + (live ? chunk_rel : 0)) * BK) * 4u;
 #pragma unroll
-        for (int j = 0; j < A4; ++j) rp[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, live ? pa_voff[j] : Y3_OOB, soff, 0);
+        for (int j = 0; j < A4; ++j)
+            rp[j] = a_nt ? __builtin_amdgcn_raw_buffer_load_b128(rs_src, live ? pa_voff[j] : Y3_OOB, soff, 2 /* nt */)
+                         : __builtin_amdgcn_raw_buffer_load_b128(rs_src, live ? pa_voff[j] : Y3_OOB, soff, 0);
     };
     auto patch_load_one = [&](auto J, int chunk_rel) {
         constexpr int j = decltype(J)::value;
         const bool live = chunk_rel < nchunks;
         const unsigned soff = (unsigned)((c0 + (live ? chunk_rel : 0)) * BK) * 4u;
-        rp[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, live ? pa_voff[j] : Y3_OOB, soff, 0);
+        rp[j] = a_nt ? __builtin_amdgcn_raw_buffer_load_b128(rs_src, live ? pa_voff[j] : Y3_OOB, soff, 2 /* nt */)
+                     : __builtin_amdgcn_raw_buffer_load_b128(rs_src, live ? pa_voff[j] : Y3_OOB, soff, 0);
     };
     auto patch_sub = [&](auto E, int pb) {         // sub-step E (0 .. 4 * A4 - 1) of the patch in rp -> patch buffer pb
         constexpr int e = decltype(E)::value, j = e / 4, sub = e % 4;
