@@ -7,7 +7,7 @@ import csv
 import json
 import sys
 
-FAMILY = ('conv_igemm', 'conv_wgrad', 'splitk_epilogue', 'slab_reduce')    # splitk_epilogue: round 1 only; slab_reduce: kernel gradients with > 8 pixel splits
+FAMILY = ('conv_igemm', 'conv_wgrad', 'conv_x3', 'splitk_epilogue', 'slab_reduce')    # splitk_epilogue: round 1 only; slab_reduce: kernel gradients with > 8 pixel splits
 path = sys.argv[1]
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else None
 spans, allspans, total, fwd_passes = [], [], 0, 0

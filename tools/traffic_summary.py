@@ -8,7 +8,7 @@ import csv
 import json
 import sys
 
-FAMILY = ('conv_igemm', 'conv_wgrad', 'splitk_epilogue', 'slab_reduce')    # splitk_epilogue: round 1 only
+FAMILY = ('conv_igemm', 'conv_wgrad', 'conv_x3', 'splitk_epilogue', 'slab_reduce')    # splitk_epilogue: round 1 only
 
 
 def total(path, counter):
