@@ -595,9 +595,9 @@ __device__ __forceinline__ void conv_x3p_body(const FastArgs& p, const int braw,
                                 read_b(G{}, C1{}, r - MB - NB, cur ^ 1);
                         });
                     } else if constexpr (q < RS2 + B_LOADS) {
-                        if (!Y3_ABL(1)) b_load_one(RS{}, std::integral_constant<int, q - RS2>{}, srel + 4, std::integral_constant<int, (u + 4) % NT>{});
+                        if (!Y3_ABL(1 | 32)) b_load_one(RS{}, std::integral_constant<int, q - RS2>{}, srel + 4, std::integral_constant<int, (u + 4) % NT>{});
                     } else if constexpr (t == 0 && q < RS2 + B_LOADS + (A4 + 1) / 2) {
-                        if (!Y3_ABL(1))
+                        if (!Y3_ABL(1 | 16))
                             y3_for_each_ic(std::make_integer_sequence<int, 2>{}, [&](auto D) {
                                 constexpr int jj = (q - RS2 - B_LOADS) * 2 + decltype(D)::value;
                                 if constexpr (jj < A4) patch_load_one(std::integral_constant<int, jj>{}, cp + cr + 1);

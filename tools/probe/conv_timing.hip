@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
     hipMemset(dt, 0, (size_t)maxwg * 8 * 8);
     const int abl = getenv("Y3_ABL") ? atoi(getenv("Y3_ABL")) : 0;     // ablation (results become wrong, timing stays meaningful)
     hipMemcpyToSymbol(HIP_SYMBOL(y3_abl_dev), &abl, sizeof(abl));
-    if (abl) printf("ablation mask %d (1 = no global loads in the K loop, 2 = no LDS stores (x3: no split either), 4 = no barrier, 8 = split-K slabs stored with the default cache policy instead of sc1)\n", abl);
+    if (abl) printf("ablation mask %d (1 = no global loads in the K loop, 2 = no LDS stores (x3: no split either), 4 = no barrier, 8 = split-K slabs stored with the default cache policy instead of sc1, x3 patch kernel: 16 = no activation loads, 32 = no weight loads)\n", abl);
     {   // the whole launch under the ablation, stamps still off (the buffer pointer is set below)
         for (int i = 0; i < 5; ++i) run();
         hipDeviceSynchronize();
