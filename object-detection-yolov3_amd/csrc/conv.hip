@@ -360,8 +360,14 @@ __device__ __forceinline__ void conv_fast_body(const FastArgs& p, const int braw
         const bool live = k0 < kend;
         o.dead = live ? 0u : Y3_OOB;
         k0 = live ? k0 : kbeg;
-        o.tap = k0 >> p.logC;  // wave-uniform: scalar unit
-        o.cb = k0 & p.cmask;
+        if (p.korder) {        // (wave-uniform: scalar unit)
+            const int step = k0 >> 4, sh = p.korder - 1, g = y3_div(step, p.dv_taps), r = step - g * (p.ntaps << sh);
+            o.tap = r >> sh;
+            o.cb = (g << (4 + sh)) + ((r & sh) << 4);
+        } else {
+            o.tap = k0 >> p.logC;
+            o.cb = k0 & p.cmask;
+        }
         const int ty = (o.tap * p.tg_mul) >> 5;                  // tap / tg_nx for tap < 9
         const int tx = o.tap - ty * p.tg_nx;
         o.toff = p.tg_off0 + ty * p.tg_offy + tx * p.tg_offx;
@@ -602,8 +608,11 @@ __global__ __launch_bounds__(64 * WM * WN, Y3_WGRAD_WAVES_EU) void conv_wgrad_ke
         split = q * 8 + xcd;
         bid = jx - q * tiles;
     } else {
-        split = y3_div((int)blockIdx.x, dv_tiles);
-        bid = y3_xcd_remap((int)blockIdx.x - split * tiles, tiles);
+        // every XCD takes one contiguous run of (pixel run, tile) items, tile fastest: the tiles of a pixel run read the same
+        // pixels of src and ddst (each at its own tap / channel block), so a run is fetched by one or two XCDs instead of all eight
+        const int item = y3_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+        split = y3_div(item, dv_tiles);
+        bid = item - split * tiles;
     }
     if (split >= splits) return;
     const int bk = y3_div(bid, dv_nbn), bn = bid - bk * nbn;
@@ -1272,6 +1281,9 @@ static bool make_fast(const ConvArgs& a, int ntaps, int bk, FastArgs* f) {
         p.tap_wrow[t] = (int)((a.tap_wsel >> (4 * t)) & 15ull) * a.C;
     }
     p.ntaps = ntaps;
+    static const int korder = env_int("Y3_KORDER", 2);      // development: 0 = taps outermost, 1 = 16-channel chunks outermost
+    p.korder = ntaps > 1 ? (korder == 2 && a.C % 32 != 0 ? 1 : korder) : 0;
+    p.dv_taps = y3_make_div(p.korder == 2 ? 2 * ntaps : ntaps);
     p.ohw = a.OH * a.OW;
     p.dv_ohw = y3_make_div(p.ohw);
     p.dv_ow = y3_make_div(a.OW);

@@ -20,6 +20,14 @@ struct FastArgs {
     const float* wt;   // [tap][C][Nout]; the x3 kernels (conv_x3.hip): the bf16 piece planes y3_x3_split_weights makes of the K-contiguous copy
     int Cper;          // channels per tap (K = ntaps * Cper)
     int x3_mode;       // x3 kernels: bit 0 = non-temporal activation loads
+    // Order of the K steps of a multi-tap launch.  korder 2: 32-channel group (one 128-byte line per pixel) outermost, taps inside,
+    // the two 16-channel halves of the line innermost: the taps of a group re-read the same few image rows, and so do the
+    // neighbouring row tiles -- all within 2 * ntaps steps, while the rows are still in L2.  korder 0 (taps outermost) spaces the
+    // three uses of an image row a third of a workgroup's life apart: the big early layers fetched their input 3-4x (rocprofv3
+    // FETCH_SIZE, profiles/r04_traffic_by_kernel.txt).  korder 1 (16-channel chunks outermost; C % 32 != 0) splits the two halves
+    // of a line by ntaps steps: worse than 0 for the 32-channel layers.  dv_taps divides by the steps of a group (ntaps << (korder - 1)).
+    int korder;
+    Y3Div dv_taps;
     float* dst;
     const float* bias;
     const float* scale;
@@ -139,7 +147,11 @@ struct FastWork {
     Y3Div dv_ohw, dv_ow;
 };
 
-template <int BM, int BN, int WM, int WN, int BK>
+// KZMAJOR (the x3 patch kernel): with column-major tile ids the items of a column are dealt K slice by K slice (row tile fastest)
+// instead of tile by tile: the run of items an XCD takes then holds ALL row tiles of a few (column, K slice) pairs -- they load
+// the same weight blocks step by step, so a block of the planes is fetched into one L2 instead of two or three.  Only who
+// computes which item changes; item ids (slab slots, tickets) stay tile-major.
+template <int BM, int BN, int WM, int WN, int BK, bool KZMAJOR = false>
 __device__ __forceinline__ FastWork conv_fast_decode(const FastArgs& p, const int braw, const int grid) {
     FastWork w;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -161,7 +173,26 @@ __device__ __forceinline__ FastWork conv_fast_decode(const FastArgs& p, const in
     const Y3Div dv_nb = {dnb_m, dnb_s}, dv_s0 = {ds0_m, ds0_s}, dv_s1 = {ds1_m, ds1_s}, dv_ohw = {dohw_m, dohw_s}, dv_ow = {dow_m, dow_s};
 
     // work item: ids are contiguous per XCD inside the two ranges [0, sk_n0) and [sk_n0, grid)
-    const int bid0 = braw < sk_n0 ? y3_xcd_remap(braw, sk_n0) : sk_n0 + y3_xcd_remap(braw - sk_n0, grid - sk_n0);
+    int bid0 = braw < sk_n0 ? y3_xcd_remap(braw, sk_n0) : sk_n0 + y3_xcd_remap(braw - sk_n0, grid - sk_n0);
+    if (KZMAJOR && col_major) {
+        const bool ra = bid0 < sk_n0;
+        const int sl = ra ? sk_s0 : sk_s1;
+        if (sl > 1) {
+            const int t0 = ra ? 0 : sk_f, t1 = ra ? sk_f : sk_f + y3_div(grid - sk_n0, dv_s1);      // tiles [t0, t1) of the range
+            int a = ra ? bid0 : bid0 - sk_n0, base = t0;
+            int n = min(t1, (y3_div(t0, dv_nb) + 1) * nb_fast) - t0;      // tiles of the range in its first column
+            if (a >= n * sl) {
+                a -= n * sl;
+                base += n;
+                const int col = a / (nb_fast * sl);                      // whole columns in front of this item's
+                a -= col * nb_fast * sl;
+                base += col * nb_fast;
+                n = min(nb_fast, t1 - base);
+            }
+            const int kzp = a / n;
+            bid0 = (ra ? 0 : sk_n0) + (base + (a - kzp * n) - t0) * sl + kzp;
+        }
+    }
     int bid, kz, nz, kchunk;
     if (bid0 < sk_n0) {
         bid = y3_div(bid0, dv_s0);

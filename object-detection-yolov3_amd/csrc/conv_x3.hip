@@ -125,8 +125,14 @@ __device__ __forceinline__ void conv_x3_body(const FastArgs& p, const int braw, 
         const bool live = k0 < kend;
         o.dead = live ? 0u : Y3_OOB;
         k0 = live ? k0 : kbeg;
-        o.tap = k0 >> p.logC;  // wave-uniform: scalar unit
-        o.cb = k0 & p.cmask;
+        if (p.korder) {        // (wave-uniform: scalar unit)
+            const int step = k0 >> 4, sh = p.korder - 1, g = y3_div(step, p.dv_taps), r = step - g * (p.ntaps << sh);
+            o.tap = r >> sh;
+            o.cb = (g << (4 + sh)) + ((r & sh) << 4);
+        } else {
+            o.tap = k0 >> p.logC;
+            o.cb = k0 & p.cmask;
+        }
         const int ty = (o.tap * p.tg_mul) >> 5;                  // tap / tg_nx for tap < 9
         const int tx = o.tap - ty * p.tg_nx;
         o.toff = p.tg_off0 + ty * p.tg_offy + tx * p.tg_offx;
@@ -392,7 +398,7 @@ __device__ __forceinline__ void conv_x3p_body(const FastArgs& p, const int braw,
         y3_timing_buf[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
-    const FastWork fw = conv_fast_decode<BM, BN, WM, WN, BK>(p, braw, grid);
+    const FastWork fw = conv_fast_decode<BM, BN, WM, WN, BK, true>(p, braw, grid);
     const int tid = fw.tid, l31 = fw.l31, lh = fw.lh, wm = fw.wm, wn = fw.wn;
     const int m0 = fw.m0, n0 = fw.n0, kbeg = fw.kbeg, kend = fw.kend;
     const int ohw = fw.ohw, OW = fw.OW, aM = fw.aM, aH = fw.aH, aW = fw.aW, src_ld = fw.src_ld, Nout = fw.Nout;
@@ -481,7 +487,7 @@ __device__ __forceinline__ void conv_x3p_body(const FastArgs& p, const int braw,
     auto patch_load_one = [&](auto J, int chunk_rel) {
         constexpr int j = decltype(J)::value;
         const bool live = chunk_rel < nchunks;
-        const unsigned soff = (unsigned)((c0 + (live ? chunk_rel : 0)) * BK) * 4u;
+        const unsigned soff = Y3_ABL(128) ? 0u : (unsigned)((c0 + (live ? chunk_rel : 0)) * BK) * 4u;
         rp[j] = a_nt ? __builtin_amdgcn_raw_buffer_load_b128(rs_src, live ? pa_voff[j] : Y3_OOB, soff, 2 /* nt */)
                      : __builtin_amdgcn_raw_buffer_load_b128(rs_src, live ? pa_voff[j] : Y3_OOB, soff, 0);
     };
@@ -498,7 +504,7 @@ __device__ __forceinline__ void conv_x3p_body(const FastArgs& p, const int braw,
         const bool live = step < nk;
         const int chunk = c0 + (live ? step : 0) / NT;
         // the step's block [(weight tap) * C / 16 + chunk][Nout rows][3 pieces][16 k]: 96 bytes per row
-        rb[set][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[e] | (live ? 0u : Y3_OOB), (s_wtap[t] + (unsigned)chunk) * (unsigned)p.Nout * 96u, 0);
+        rb[set][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, b_voff[e] | (live ? 0u : Y3_OOB), Y3_ABL(64) ? 0u : (s_wtap[t] + (unsigned)chunk) * (unsigned)p.Nout * 96u, 0);
     };
     auto b_sub = [&](auto S, auto E, int buf) {      // weight load E: 16 bytes straight into its (piece, k half, row) slot
         constexpr int set = decltype(S)::value, e = decltype(E)::value;
@@ -717,8 +723,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_x3_kernel(const Wg
         split = q * 8 + xcd;
         bid = jx - q * tiles;
     } else {
-        split = y3_div((int)blockIdx.x, dv_tiles);
-        bid = y3_xcd_remap((int)blockIdx.x - split * tiles, tiles);
+        // every XCD takes one contiguous run of (pixel run, tile) items, tile fastest: the tiles of a pixel run read the same
+        // pixels of src and ddst (each at its own tap / channel block), so a run is fetched by one or two XCDs instead of all eight
+        const int item = y3_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+        split = y3_div(item, dv_tiles);
+        bid = item - split * tiles;
     }
     if (split >= splits) return;
     const int bk = y3_div(bid, dv_nbn), bn = bid - bk * nbn;

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "../include/yolo3hip.h"
@@ -76,7 +77,29 @@ static void check_conv_plan(const char* what, int m, int cin, int k, int cout, u
     REQUIRE(ws >= HEADER, "%s: workspace smaller than its header", what);
     std::vector<unsigned char> seen((size_t)grid, 0), slices((size_t)tiles, 0);
     for (int b = 0; b < grid; ++b) {
-        const int item = b < n0 ? xcd_remap(b, n0) : n0 + xcd_remap(b - n0, grid - n0);
+        int item = b < n0 ? xcd_remap(b, n0) : n0 + xcd_remap(b - n0, grid - n0);
+        if ((flags & Y3_CONV_X3) && k == 3) {
+            // conv_fast_decode<KZMAJOR> (x3 patch kernel, column-major tile ids): the items of a column are dealt K slice by K slice
+            const bool ra = item < n0;
+            const int sl = ra ? s0 : s1, nb = cdiv(m, bm);
+            if (sl > 1) {
+                const int t0 = ra ? 0 : f, t1 = ra ? f : tiles;
+                int a = ra ? item : item - n0, base = t0;
+                int n = std::min(t1, (t0 / nb + 1) * nb) - t0;
+                if (a >= n * sl) {
+                    a -= n * sl;
+                    base += n;
+                    const int col = a / (nb * sl);
+                    a -= col * nb * sl;
+                    base += col * nb;
+                    n = std::min(nb, t1 - base);
+                }
+                REQUIRE(n > 0, "%s: empty column in the K-slice-major deal (block %d)", what, b);
+                if (n <= 0) continue;
+                const int kzp = a / n;
+                item = (ra ? 0 : n0) + (base + (a - kzp * n) - t0) * sl + kzp;
+            }
+        }
         REQUIRE(item >= 0 && item < grid, "%s: item %d of %d", what, item, grid);
         if (item < 0 || item >= grid) continue;
         REQUIRE(!seen[item], "%s: item %d drawn twice", what, item);

@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
     hipMemset(dt, 0, (size_t)maxwg * 8 * 8);
     const int abl = getenv("Y3_ABL") ? atoi(getenv("Y3_ABL")) : 0;     // ablation (results become wrong, timing stays meaningful)
     hipMemcpyToSymbol(HIP_SYMBOL(y3_abl_dev), &abl, sizeof(abl));
-    if (abl) printf("ablation mask %d (1 = no global loads in the K loop, 2 = no LDS stores (x3: no split either), 4 = no barrier, 8 = split-K slabs stored with the default cache policy instead of sc1, x3 patch kernel: 16 = no activation loads, 32 = no weight loads)\n", abl);
+    if (abl) printf("ablation mask %d (1 = no global loads in the K loop, 2 = no LDS stores (x3: no split either), 4 = no barrier, 8 = split-K slabs stored with the default cache policy instead of sc1, x3 patch kernel: 16 = no activation loads, 32 = no weight loads, 64 = every weight load reads the first K block (always cached), 128 = every activation load reads the first channel chunk)\n", abl);
     {   // the whole launch under the ablation, stamps still off (the buffer pointer is set below)
         for (int i = 0; i < 5; ++i) run();
         hipDeviceSynchronize();
@@ -113,6 +113,24 @@ int main(int argc, char** argv) {
     printf("CUs used %zu; workgroups per CU:", per_cu.size());
     for (auto& kv : hist) printf("  %d x%d", kv.first, kv.second);
     printf("\n");
+    if (getenv("Y3_PAIRS")) {      // which workgroup ids share a CU (two resident per CU): distance of their ids, and id % 8 against XCC_ID
+        std::map<unsigned long long, std::vector<int>> ids;
+        int xcc_match = 0, n = 0;
+        for (int i = 0; i < maxwg; ++i) {
+            if (t[(size_t)i * 8] == 0) continue;
+            const unsigned hw = (unsigned)t[(size_t)i * 8 + 4], xcc = (unsigned)t[(size_t)i * 8 + 5] & 0xf;
+            const unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+            ids[((unsigned long long)xcc << 16) | (se << 8) | (sh << 4) | cu].push_back(i);
+            xcc_match += (unsigned)(i % 8) == xcc;
+            ++n;
+        }
+        std::map<int, int> dist;
+        for (auto& kv : ids)
+            if (kv.second.size() == 2) dist[kv.second[1] - kv.second[0]]++;
+        printf("id %% 8 == XCC_ID for %d of %d workgroups; id distance of the two workgroups of a CU:", xcc_match, n);
+        for (auto& kv : dist) printf("  %d x%d", kv.first, kv.second);
+        printf("\n");
+    }
     // SIMD-cycles of MFMA in the whole launch: 4096 flop per 64 cycles (v_mfma_f32_32x32x2_f32); x3: 6 x 32768 flop-equivalents per 32 cycles each
     const double total_mfma_cycles = x3 ? flop * 6.0 / 32768.0 * 32.0 : flop / 4096.0 * 64.0;
     printf("MFMA floor: %.0f cycles per SIMD if spread evenly over %zu CUs x 4 SIMDs\n", total_mfma_cycles / (per_cu.size() * 4.0), per_cu.size());

@@ -1,0 +1,7 @@
+# development: are the loads of the x3 patch kernel slow because they miss (64 / 128: same instructions, always-cached addresses)?
+P=tools/probe/conv_timing
+for shape in "8 52 128 256 3" "8 26 256 512 3" "8 13 512 1024 3"; do
+  for abl in 0 64 128 192 1; do
+    echo "=== x3 $shape | Y3_ABL=$abl"; Y3_ABL=$abl $P $shape 1 | grep -E "^layer|under ablation|shader clock|prologue|main loop|epilogue|whole workgroup" || exit 1
+  done
+done
