@@ -45,7 +45,7 @@ def planes(w):
 
 if args.wgrad:
     shapes = [(52, 128, 256, 3, 1), (26, 256, 512, 3, 1), (13, 512, 1024, 3, 1), (104, 64, 128, 3, 1), (104, 128, 256, 3, 2), (52, 256, 512, 3, 2), (26, 512, 1024, 3, 2),
-              (52, 256, 128, 1, 1), (26, 512, 256, 1, 1), (13, 1024, 512, 1, 1)]
+              (52, 256, 128, 1, 1), (26, 512, 256, 1, 1), (13, 1024, 512, 1, 1), (208, 32, 64, 3, 1), (416, 32, 64, 3, 2), (208, 64, 32, 1, 1), (104, 128, 64, 1, 1)]
     for (hh, cin, cout, k, s_) in shapes:
         oh = hh // s_
         xd = torch.randn(N, hh, hh, cin, device='cuda')
