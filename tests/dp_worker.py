@@ -62,7 +62,7 @@ def main():
     np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), grads=yolo.grads.cpu().numpy(), params=yolo.params.cpu().numpy(),
              moving=yolo.moving.cpu().numpy(), adam_m=yolo.adam_m.cpu().numpy(), loss=float(loss), buckets=len(strategy.buckets),
              collectives=len(stats.get('allreduce_ms_per_bucket', [])), communicator_ranks=int(info['communicator_ranks']),
-             rccl_version=str(info.get('rccl_version')))
+             rccl_version=str(info.get('rccl_version')), ranks_summed=int(info['ranks_summed']))
     strategy.close()
     dist.barrier()
     dist.destroy_process_group()

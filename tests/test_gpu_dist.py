@@ -145,7 +145,7 @@ def test_rccl_backend_one_rank_forced_collectives_equal_plain_step(tmp_path, tra
         d.mkdir()
         z = _run_one_rank(str(d), img, n, seed, ws, 'nccl', transport)
         assert int(z['buckets']) >= 2 and int(z['collectives']) == int(z['buckets'])      # every bucket really was all-reduced
-        assert int(z['communicator_ranks']) == 1
+        assert int(z['communicator_ranks']) == 1 and int(z['ranks_summed']) == 1      # ones through the gradient path (RCCL's stream)
         for k, v in want.items():
             assert np.array_equal(z[k], v), 'wgrad stream %s, %s transport: %s differs from the plain step' % (ws, transport, k)
         assert abs(float(z['loss']) - loss) <= 1e-6 * abs(loss)
