@@ -1030,8 +1030,6 @@ static ConvPlan plan_conv_x3(int M, int Nout, int K, int ntaps) {
     {
         static const int force_bn = env_int("Y3_X3_BN", 0);      // development: 64 = 128 x 64 tiles everywhere
         if (force_bn == 64 || force_bn == 128) pl.t.bn = Nout <= 64 ? 64 : force_bn;
-        static const int small = env_int("Y3_X3_SMALL", 0);      // development: 64 x 64 tiles (two waves) for the 1x1 launches
-        if (small && ntaps == 1) pl.t = {64, 64, 16};
     }
     const int tiles = y3_cdiv(M, pl.t.bm) * y3_cdiv(Nout, pl.t.bn);
     const int nk = K / 16;

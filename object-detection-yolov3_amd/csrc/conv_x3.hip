@@ -1060,7 +1060,7 @@ extern "C" int y3_x3_split_weights_batched(const float* arena, void* planes_aren
 }
 
 // Tiles this file is built for (conv.hip plans with them): false if (bm, bn) is not one of them.
-bool y3_x3_tile_ok(int bm, int bn) { return (bm == 128 && (bn == 128 || bn == 64)) || (bm == 64 && bn == 64); }
+bool y3_x3_tile_ok(int bm, int bn) { return bm == 128 && (bn == 128 || bn == 64); }
 
 // The patch kernel takes a launch when: 3x3 stride 1 with the standard tap grid (dense destination), the patch fits the LDS rows
 // (BM + 2 (W + 1) <= Y3_X3P_ROWS), and every K slice is a whole, even number of 16-channel chunks (18 K steps).
@@ -1095,8 +1095,6 @@ bool y3_x3_launch(const FastArgs& p, int bm, int bn, bool dense, int grid, hipSt
         x3_launch_tile<128, 128, 2, 2>(p, dense, grid, st);
     else if (bm == 128 && bn == 64)
         x3_launch_tile<128, 64, 2, 1>(p, dense, grid, st);
-    else if (bm == 64 && bn == 64)
-        x3_launch_tile<64, 64, 2, 1>(p, dense, grid, st);
     else
         return false;
     return true;
