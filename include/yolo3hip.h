@@ -50,8 +50,8 @@ int y3_version(void);
  * with the flag: the kernel needs K contiguous per output column AND the weights already split, so `wt` / `wt_t` then point at the
  * THREE bf16 PLANES y3_x3_split_weights() makes of the copy with that layout -- y3_conv2d_fwd: of [tap][Cout][Cin] (what
  * y3_transpose_weights writes), y3_conv2d_dgrad*: of [tap][Cin][Cout] (the Keras kernel); each entry point the copy the OTHER one
- * takes without the flag.  (The activations are split inside the kernels.)  Shapes: y3_conv2d_x3_ok(); stride-2 data gradients are
- * not built.  Everything else -- epilogue, statistics, split-K workspace contract -- is unchanged; ask the *_x queries for tile
+ * takes without the flag.  (The activations are split inside the kernels.)  Shapes: y3_conv2d_x3_ok() / y3_conv2d_dgrad_x3_ok().
+ * Everything else -- epilogue, statistics, split-K workspace contract -- is unchanged; ask the *_x queries for tile
  * counts and workspace sizes.  y3_conv2d_wgrad_x takes the same flag (both its operands are activations: no planes involved). */
 #define Y3_CONV_X3 4u
 /* The weight operand of the Y3_CONV_X3 forward / data-gradient kernels.  w: a kernel with K contiguous per row, [taps][rows][k_per_row]
@@ -110,6 +110,10 @@ size_t y3_conv2d_fwd_workspace_x(int m, int cin, int ksize, int cout, unsigned f
  * columns (forward: c = Cin, nout = Cout; stride-1 data gradient: c = Cout, nout = Cin): c a multiple of 16 (a power of two when
  * ntaps > 1), nout >= 32. */
 int y3_conv2d_x3_ok(int m, int c, int ntaps, int nout);
+/* 1 if y3_conv2d_dgrad / y3_conv2d_dgrad_bn take this data gradient with Y3_CONV_X3: stride 1 as y3_conv2d_x3_ok(m, Cout, ksize^2,
+ * Cin); stride 2 (3x3: the merged launch of the four output-parity classes, each with its own K slices): Cin >= 64, Cout a power of
+ * two >= 32.  (tape.gradient through the stride-2 convs of darknet-53, model.py:496 / :362-366.) */
+int y3_conv2d_dgrad_x3_ok(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc);
 /* Diagnostics (host only, no launch): the plan y3_conv2d_fwd and the stride-1 y3_conv2d_dgrad use for an implicit GEMM of
  * m x cout x (ksize^2 * cin).  out13 = {bm, bn, bk, tiles, f, s0, s1, chunk0, chunk1, grid, stats_tiles, fast, nk}: tiles
  * [0, f) are cut into s0 K slices of chunk0 K steps, tiles [f, tiles) into s1 of chunk1 (nk K steps in all); grid = work

@@ -545,10 +545,6 @@ __global__ __launch_bounds__(64 * WM * WN, (BNS && BM * BN <= 64 * 64) ? 8 : 3) 
 // Up to four independent gather-GEMMs in ONE launch: the (row parity, column parity) classes of a stride-2 data gradient.
 // Each class has its own tap list, K and destination lattice; block ranges [first[c], first[c+1]) select the class.  As
 // separate launches the four small grids ran one after the other, each with its own ramp-up and tail.
-struct FastArgs4 {
-    FastArgs a[4];
-    int first[5];
-};
 template <int BM, int BN, int WM, int WN, int BK, bool BNS = false>
 __global__ __launch_bounds__(64 * WM * WN, 3) void conv_igemm_fast_multi_kernel(const FastArgs4 m) {
     int c = 0;
@@ -1513,6 +1509,20 @@ extern "C" int y3_conv2d_fwd(const y3_tensor* src, const float* wt, const float*
     return launch_igemm(p, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc, unsigned flags,
+                             const y3_tensor* bn_a, float* bn_partials, void* workspace, size_t workspace_bytes, y3_stream_t stream,
+                             int* dry_rows = nullptr, size_t* dry_ws = nullptr);
+// shapes the x3 data gradient takes: stride 1 as the forward; stride 2 (3x3, the merged launch of the parity classes): >= 64 input
+// channels of the layer (output columns of the GEMM), its output channels a power of two
+static bool dgrad_x3(unsigned flags, const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc) {
+    if (!(flags & Y3_CONV_X3) || !ddst || !dsrc) return false;
+    if (stride == 1) return x3_shape_ok(ddst->c, dsrc->c, ksize * ksize * ddst->c, ksize * ksize);
+    return stride == 2 && ksize == 3 && dsrc->c >= 64 && y3_is_pow2(ddst->c) && x3_shape_ok(ddst->c, dsrc->c, ddst->c, 1);
+}
+extern "C" int y3_conv2d_dgrad_x3_ok(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc) {
+    return dgrad_x3(Y3_CONV_X3, ddst, ksize, stride, dsrc) ? 1 : 0;
+}
+
 extern "C" size_t y3_conv2d_dgrad_workspace(const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc) {
     return y3_conv2d_dgrad_workspace_x(ddst, ksize, stride, dsrc, 0u);
 }
@@ -1522,6 +1532,11 @@ extern "C" size_t y3_conv2d_dgrad_workspace_x(const y3_tensor* ddst, int ksize, 
         const int K = taps * ddst->c;
         const bool x3 = (flags & Y3_CONV_X3) && x3_shape_ok(ddst->c, dsrc->c, K, taps);
         return plan_conv(dsrc->n * dsrc->h * dsrc->w, dsrc->c, K, fast_shape_ok(ddst->c, dsrc->c, K, taps), x3, taps).ws_bytes;
+    }
+    if (dgrad_x3(flags, ddst, ksize, stride, dsrc)) {      // the merged x3 launch: slabs of all classes behind one ticket header
+        int rows = 0;
+        size_t ws = 0;
+        if (conv2d_dgrad_impl(ddst, nullptr, ksize, 2, dsrc, Y3_CONV_X3, nullptr, nullptr, nullptr, 0, nullptr, &rows, &ws) == Y3_OK && rows > 0) return ws;
     }
     size_t best = 0;
     for (int nt = 1; nt <= 4; nt *= 2) {  // parity classes carry 1, 2, 2 and 4 taps of a 3x3 kernel
@@ -1533,12 +1548,120 @@ extern "C" size_t y3_conv2d_dgrad_workspace_x(const y3_tensor* ddst, int ksize, 
     return best;
 }
 
+// The merged stride-2 data gradient on the x3 kernels (conv_x3_multi_kernel).  The classes carry 1 / 2 / 2 / 4 taps, i.e. K steps
+// in the ratio 1 : 2 : 2 : 4, and the x3 loop wants the launch to fill the 512 workgroup slots once: every class is cut along K
+// into slices of about the same length L -- the smallest L for which the launch still fits the slots.
+struct MultiX3Plan {
+    int bn, tiles[4], s[4], chunk[4], grid, rows;
+    size_t ws;
+};
+static bool plan_dgrad_multi_x3(const ConvArgs* cls, int ncls, MultiX3Plan* pl) {
+    if (ncls < 2 || ncls > 4) return false;
+    const int Nout = cls[0].Nout;
+    if (Nout < 64) return false;
+    pl->bn = Nout >= 128 ? 128 : 64;
+    static const int slots = env_int("Y3_X3_SLOTS", 512);
+    int steps[4], tsum = 0, smax = 0;
+    long long total = 0;
+    pl->rows = 0;
+    for (int c = 0; c < ncls; ++c) {
+        const int ntaps = cls[c].K / cls[c].C;
+        if (cls[c].Nout != Nout || !x3_shape_ok(cls[c].C, Nout, cls[c].K, ntaps)) return false;
+        pl->tiles[c] = y3_cdiv(cls[c].M, 128) * y3_cdiv(Nout, pl->bn);
+        pl->rows += y3_cdiv(cls[c].M, 128);
+        steps[c] = cls[c].K / 16;
+        pl->s[c] = 1;
+        pl->chunk[c] = even_steps(steps[c]);
+        tsum += pl->tiles[c];
+        total += (long long)pl->tiles[c] * steps[c];
+        smax = steps[c] > smax ? steps[c] : smax;
+    }
+    if (tsum < slots && tsum <= Y3_MAX_TICKETS) {
+        int L = even_steps(y3_cdiv(total, slots));
+        if (L < 12) L = 12;
+        for (; L < smax; L += 2) {
+            long long g = 0;
+            for (int c = 0; c < ncls; ++c) g += (long long)pl->tiles[c] * y3_cdiv(steps[c], L);
+            if (g <= slots) break;
+        }
+        for (int c = 0; c < ncls; ++c) {
+            const int sc = y3_cdiv(steps[c], L);
+            if (sc > 1) {
+                pl->chunk[c] = even_steps(y3_cdiv(steps[c], sc));
+                pl->s[c] = y3_cdiv(steps[c], pl->chunk[c]);
+            }
+        }
+    }
+    pl->grid = 0;
+    size_t slab = 0;
+    for (int c = 0; c < ncls; ++c) {
+        pl->grid += pl->tiles[c] * pl->s[c];
+        if (pl->s[c] > 1) slab += (size_t)pl->tiles[c] * pl->s[c] * 128 * pl->bn * 4;
+    }
+    pl->ws = slab ? (size_t)Y3_WS_HEADER + slab : 0;
+    return true;
+}
+static bool launch_dgrad_multi_x3(const ConvArgs* cls, int ncls, hipStream_t st, int* dry, size_t* dry_ws, void* workspace, size_t workspace_bytes) {
+    MultiX3Plan pl;
+    if (!plan_dgrad_multi_x3(cls, ncls, &pl)) return false;
+    if (!dry && pl.ws > 0 && (workspace == nullptr || workspace_bytes < pl.ws)) {      // no room for slabs: whole tiles
+        for (int c = 0; c < ncls; ++c) {
+            pl.s[c] = 1;
+            pl.chunk[c] = even_steps(cls[c].K / 16);
+        }
+        pl.ws = 0;
+    }
+    FastArgs4 m = {};
+    int first = 0, rows = 0, tick = 0;
+    size_t slab_floats = 0;
+    for (int c = 0; c < ncls; ++c) {
+        const int ntaps = cls[c].K / cls[c].C;
+        if (!make_fast(cls[c], ntaps, 16, &m.a[c])) return false;
+        FastArgs& a = m.a[c];
+        a.nbn = y3_cdiv(cls[c].Nout, pl.bn);
+        a.nbm = y3_cdiv(cls[c].M, 128);
+        a.col_major = 0;
+        a.nb_fast = a.nbn;
+        a.dv_nb = y3_make_div(a.nbn);
+        a.dv_s0 = a.dv_s1 = y3_make_div(pl.s[c]);
+        a.sk_f = pl.tiles[c];
+        a.sk_s0 = a.sk_s1 = pl.s[c];
+        a.sk_n0 = pl.tiles[c] * pl.s[c];
+        a.sk_chunk0 = a.sk_chunk1 = pl.chunk[c];
+        a.sk_slab0 = 0;
+        const bool split = pl.s[c] > 1 && pl.ws > 0;
+        const bool have = split && workspace != nullptr;      // (dry runs plan without a workspace)
+        a.tickets = have ? (int*)workspace + tick : nullptr;
+        a.slab = have ? (float*)((char*)workspace + Y3_WS_HEADER) + slab_floats : nullptr;
+        if (split) {
+            tick += pl.tiles[c];
+            slab_floats += (size_t)pl.tiles[c] * pl.s[c] * 128 * pl.bn;
+        }
+        a.bn_row0 = rows;
+        rows += a.nbm;
+        m.first[c] = first;
+        first += pl.tiles[c] * pl.s[c];
+    }
+    for (int c = ncls; c <= 4; ++c) m.first[c] = first;
+    if (dry) {
+        *dry = rows;
+        if (dry_ws) *dry_ws = pl.ws;
+        return true;
+    }
+    if (pl.ws > 0)
+        if (check_tickets("conv2d_dgrad (stride 2, x3)", workspace, st) != Y3_OK) return false;
+    return y3_x3_multi_launch(m, pl.bn, cls[0].bn_a != nullptr, first, st);
+}
+
 // One launch for all parity classes of a stride-2 data gradient; false if the shapes do not qualify (the caller then
 // launches the classes one by one).
 // dry != nullptr: nothing is launched, *dry receives the number of partial-statistics rows (row tiles over all classes)
-static bool launch_dgrad_multi(const ConvArgs* cls, int ncls, hipStream_t st, int* dry = nullptr) {
+static bool launch_dgrad_multi(const ConvArgs* cls, int ncls, hipStream_t st, int* dry = nullptr, size_t* dry_ws = nullptr, void* workspace = nullptr,
+                              size_t workspace_bytes = 0) {
     static const int off = env_int("Y3_NO_DGRAD_MULTI", 0);
     if (off || ncls < 2 || ncls > 4) return false;
+    if (cls[0].x3) return launch_dgrad_multi_x3(cls, ncls, st, dry, dry_ws, workspace, workspace_bytes);
+    if (dry_ws) *dry_ws = 0;
     FastArgs4 m = {};
     int mmax = 0;
     for (int c = 0; c < ncls; ++c) mmax = cls[c].M > mmax ? cls[c].M : mmax;
@@ -1594,13 +1717,6 @@ static bool launch_dgrad_multi(const ConvArgs* cls, int ncls, hipStream_t st, in
     return true;
 }
 
-static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc, unsigned flags,
-                             const y3_tensor* bn_a, float* bn_partials, void* workspace, size_t workspace_bytes, y3_stream_t stream,
-                             int* dry_rows = nullptr);
-static bool dgrad_x3(unsigned flags, const y3_tensor* ddst, int ksize, int stride, const y3_tensor* dsrc) {
-    return (flags & Y3_CONV_X3) && stride == 1 && ddst && dsrc && x3_shape_ok(ddst->c, dsrc->c, ksize * ksize * ddst->c, ksize * ksize);
-}
-
 extern "C" int y3_conv2d_dgrad(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc, unsigned flags,
                                void* workspace, size_t workspace_bytes, y3_stream_t stream) {
     return conv2d_dgrad_impl(ddst, wt_t, ksize, stride, dsrc, flags, nullptr, nullptr, workspace, workspace_bytes, stream);
@@ -1616,7 +1732,8 @@ extern "C" int y3_conv2d_dgrad_bn_tiles_x(const y3_tensor* ddst, int ksize, int 
     if (stride == 2) {      // the merged launch of the four parity classes: rows of all classes, or 0 if it would not be taken
         if (ksize != 3 || ddst->h != (dsrc->h + 1) / 2 || ddst->w != (dsrc->w + 1) / 2 || ddst->n != dsrc->n) return 0;
         int rows = 0;
-        if (conv2d_dgrad_impl(ddst, nullptr, ksize, 2, dsrc, 0, nullptr, nullptr, nullptr, 0, nullptr, &rows) != Y3_OK) return 0;
+        const unsigned x3f = dgrad_x3(flags, ddst, ksize, stride, dsrc) ? Y3_CONV_X3 : 0u;
+        if (conv2d_dgrad_impl(ddst, nullptr, ksize, 2, dsrc, x3f, nullptr, nullptr, nullptr, 0, nullptr, &rows) != Y3_OK) return 0;
         return rows;
     }
     if (stride != 1) return 0;
@@ -1644,7 +1761,7 @@ extern "C" int y3_conv2d_dgrad_bn(const y3_tensor* ddst, const float* wt_t, int 
 
 static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize, int stride, const y3_tensor* dsrc, unsigned flags,
                              const y3_tensor* bn_a, float* bn_partials, void* workspace, size_t workspace_bytes, y3_stream_t stream,
-                             int* dry_rows) {
+                             int* dry_rows, size_t* dry_ws) {
     if (!dry_rows) {      // dry run (y3_conv2d_dgrad_bn_tiles, stride 2): geometry only, pointers may be null
         if (int e = check_tensor(ddst, "conv2d_dgrad ddst")) return e;
         if (int e = check_tensor(dsrc, "conv2d_dgrad dsrc")) return e;
@@ -1655,7 +1772,7 @@ static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize
     const int OH = (dsrc->h + stride - 1) / stride, OW = (dsrc->w + stride - 1) / stride;
     Y3_CHECK_ARG(ddst->n == dsrc->n && ddst->h == OH && ddst->w == OW, "conv2d_dgrad: geometry mismatch");
     Y3_CHECK_ARG((flags & ~(Y3_EPI_ACCUM | Y3_CONV_X3)) == 0, "conv2d_dgrad: only Y3_EPI_ACCUM and Y3_CONV_X3 allowed");
-    Y3_CHECK_ARG(!(flags & Y3_CONV_X3) || dgrad_x3(flags, ddst, ksize, stride, dsrc), "conv2d_dgrad: Y3_CONV_X3 takes stride-1 shapes that pass y3_conv2d_x3_ok()");
+    Y3_CHECK_ARG(!(flags & Y3_CONV_X3) || dgrad_x3(flags, ddst, ksize, stride, dsrc), "conv2d_dgrad: Y3_CONV_X3 does not take this shape (ask y3_conv2d_dgrad_x3_ok())");
     const int pbh = y3_same_pad_before(dsrc->h, ksize, stride), pbw = y3_same_pad_before(dsrc->w, ksize, stride);
     // the contraction runs over (tap, cout): channels of ddst
     ConvArgs base = {};
@@ -1758,10 +1875,10 @@ static int conv2d_dgrad_impl(const y3_tensor* ddst, const float* wt_t, int ksize
     if (dry_rows) {
         *dry_rows = 0;
         int rows = 0;
-        if (launch_dgrad_multi(cls, ncls, (hipStream_t)stream, &rows)) *dry_rows = rows;
+        if (launch_dgrad_multi(cls, ncls, (hipStream_t)stream, &rows, dry_ws)) *dry_rows = rows;
         return Y3_OK;
     }
-    if (launch_dgrad_multi(cls, ncls, (hipStream_t)stream)) {
+    if (launch_dgrad_multi(cls, ncls, (hipStream_t)stream, nullptr, nullptr, workspace, workspace_bytes)) {
         Y3_CHECK_LAUNCH("conv_igemm_fast_multi");
         return Y3_OK;
     }

@@ -136,6 +136,13 @@ bool y3_wgrad_x3_launch(const WgradArgs& p, int bkr, int bn, unsigned grid, hipS
 
 // conv_x3.hip: launch of the x3 kernel for a planned tile (false: no kernel built for it)
 bool y3_x3_launch(const FastArgs& p, int bm, int bn, bool dense, int grid, hipStream_t st);
+// Up to four independent gather-GEMMs in ONE launch: the (row parity, column parity) classes of a stride-2 data gradient.
+// Each class has its own tap list, K, destination lattice and (x3) K slices; block ranges [first[c], first[c+1]) select the class.
+struct FastArgs4 {
+    FastArgs a[4];
+    int first[5];
+};
+bool y3_x3_multi_launch(const FastArgs4& m, int bn, bool bns, int grid, hipStream_t st);
 bool y3_x3_tile_ok(int bm, int bn);
 
 // One workgroup's share of a launch, decoded from its (XCD-remapped) block index.

@@ -657,6 +657,33 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3_kernel(const FastArgs
     conv_x3_body<BM, BN, WM, WN, DENSE, BNS>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// The four parity classes of a stride-2 data gradient in one launch (conv.hip: conv_igemm_fast_multi_kernel), on the x3
+// arithmetic: every class brings its own K slices, tickets and slabs.
+template <int BM, int BN, int WM, int WN, bool BNS>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3_multi_kernel(const FastArgs4 m) {
+    int c = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) c += ((int)blockIdx.x >= m.first[i]) ? 1 : 0;
+    conv_x3_body<BM, BN, WM, WN, false, BNS>(m.a[c], (int)blockIdx.x - m.first[c], m.first[c + 1] - m.first[c]);
+}
+bool y3_x3_multi_launch(const FastArgs4& m, int bn, bool bns, int grid, hipStream_t st) {
+    const dim3 g(grid);
+    if (bn == 128) {
+        if (bns)
+            hipLaunchKernelGGL((conv_x3_multi_kernel<128, 128, 2, 2, true>), g, dim3(256), 0, st, m);
+        else
+            hipLaunchKernelGGL((conv_x3_multi_kernel<128, 128, 2, 2, false>), g, dim3(256), 0, st, m);
+    } else if (bn == 64) {
+        if (bns)
+            hipLaunchKernelGGL((conv_x3_multi_kernel<128, 64, 2, 1, true>), g, dim3(128), 0, st, m);
+        else
+            hipLaunchKernelGGL((conv_x3_multi_kernel<128, 64, 2, 1, false>), g, dim3(128), 0, st, m);
+    } else {
+        return false;
+    }
+    return true;
+}
+
 template <int BM, int BN, int WM, int WN>
 static void x3_launch_tile(const FastArgs& p, bool dense, int grid, hipStream_t st) {
     const dim3 g(grid), b(64 * WM * WN);

@@ -756,6 +756,12 @@ class YoloV3:
         return self._x3_policy(sp.cin_pad, sp.k * sp.k, sp.cout, m_out, sp.s, True)
 
     def x3_dgrad(self, sp, m_in):
+        if sp.s == 2:
+            # the merged launch of the four parity classes (y3_conv2d_dgrad_x3_ok): >= 64 input channels, output channels a power of two
+            if self.conv_arithmetic == 'f32' or sp.k != 3 or sp.cin_pad < 64 or sp.cout % 16 or (sp.cout & (sp.cout - 1)):
+                return False
+            # measured (tools/layer_times.py): 163 -> 125, 151 -> 124, 142 -> 103 us at 13^2 / 26^2 / 52^2 output; 152 -> 151 for the 64-channel layer
+            return self.conv_arithmetic == 'x3-all' or sp.cin_pad >= 128
         return self._x3_policy(sp.cout, sp.k * sp.k, sp.cin_pad, m_in, sp.s, False)
 
     def x3_wgrad(self, sp, m_out):

@@ -220,6 +220,17 @@ int main(int argc, char** argv) {
                 snprintf(name, sizeof name, "dgrad[%zu]/taps%d", i, nt);
                 check_conv_plan(name, batch * ((in + 1) / 2) * ((in + 1) / 2), nt * l.cout, 1, l.cin);
             }
+            if (y3_conv2d_dgrad_x3_ok(&dd, l.k, l.s, &ds)) {      // the merged launch on the x3 kernels: per-class K slices behind one ticket header
+                const size_t xws = y3_conv2d_dgrad_workspace_x(&dd, l.k, l.s, &ds, Y3_CONV_X3);
+                const int xrows = y3_conv2d_dgrad_bn_tiles_x(&dd, l.k, l.s, &ds, Y3_CONV_X3);
+                int want = 0;
+                for (int ph = 0; ph < 2; ++ph)
+                    for (int pw = 0; pw < 2; ++pw) want += cdiv(batch * ((in - ph + 1) / 2) * ((in - pw + 1) / 2), 128);
+                printf("dgrad_x3_s2[%zu] ws=%zu bn_tiles=%d\n", i, xws, xrows);
+                REQUIRE(xrows == want || xrows == 0 /* merged launch switched off: Y3_NO_DGRAD_MULTI */, "dgrad_x3_s2[%zu]: %d statistics rows, the four classes have %d row tiles of 128", i, xrows, want);
+                // at most one slice per workgroup slot (512; the development switch goes up to 1000) of 128 x 128 floats behind the header, or no split at all
+                REQUIRE(xws == 0 || (xws > HEADER && xws <= HEADER + (size_t)(1024 + 4 * cdiv(l.cin, 64)) * 128 * 128 * 4), "dgrad_x3_s2[%zu]: workspace %zu", i, xws);
+            }
         }
         const size_t dws = y3_conv2d_dgrad_workspace(&dd, l.k, l.s, &ds);
         const int rows = y3_conv2d_dgrad_bn_tiles(&dd, l.k, l.s, &ds);
