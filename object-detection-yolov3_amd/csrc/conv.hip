@@ -1081,6 +1081,22 @@ static ConvPlan plan_conv_x3(int M, int Nout, int K, int ntaps) {
             pl.s0 = pl.s1 = s_lo;
             pl.chunk0 = pl.chunk1 = c_lo;
         }
+        // Overflow by SHORT slices: when the next larger count leaves a last slice of at most a third of the others and the launch
+        // has a multiple of 8 column tiles, every XCD's run of items (K-slice-major within a column: conv_fast_decode<KZMAJOR>) ENDS
+        // with those short slices, so the few blocks beyond the slots are short ones that start as the first short ones finish --
+        // and no tile needs the longer slices of s_lo (13x13 forward: 88 x 6 = 528 pieces of 54 / 18 steps instead of 80 x 6 + 8 x 4
+        // with 72-step pieces: 92 -> 82 us).
+        static const int overflow_on = env_int("Y3_X3_OVERFLOW", 1);
+        const int nbn = y3_cdiv(Nout, pl.t.bn);
+        if (c_hi > 0 && overflow_on && !force_ks && ntaps == 9 && nbn % 8 == 0) {
+            const int s_hi = count_for(c_hi), last = nk - (s_hi - 1) * c_hi;
+            if ((long long)tiles * s_hi <= slots + slots / 16 && 3 * last <= c_hi) {
+                pl.f = tiles;
+                pl.s0 = pl.s1 = s_hi;
+                pl.chunk0 = pl.chunk1 = c_hi;
+                c_hi = 0;
+            }
+        }
         if (c_hi > 0) {      // tiles [0, f) take the next larger count: f * s_hi + (tiles - f) * s_lo <= slots
             const int s_hi = count_for(c_hi);
             const int f = (int)((slots - (long long)tiles * s_lo) / (s_hi - s_lo));

@@ -79,7 +79,8 @@ def test_product_build_ignores_development_switches(sweeps):
     exe, _ = sweeps
     base = _run(exe, [8, 416])
     assert _run(exe, [8, 416], {'Y3_TILE': '64,64,16', 'Y3_RSPLIT': '0', 'Y3_SPLITK_WGS': '500', 'Y3_WGRAD_WAVES': '1024', 'Y3_PIPE': '1'}) == base
-    assert _run(exe, [8, 416], {'Y3_X3_SLOTS': '1000', 'Y3_X3_KS': '3', 'Y3_X3_BN': '64', 'Y3_X3_RSPLIT': '0', 'Y3_WGX3_WGS': '900', 'Y3_BNB_LC': '4', 'Y3_BNB_BLOCKS': '64'}) == base
+    assert _run(exe, [8, 416], {'Y3_X3_SLOTS': '1000', 'Y3_X3_KS': '3', 'Y3_X3_BN': '64', 'Y3_X3_RSPLIT': '0', 'Y3_WGX3_WGS': '900', 'Y3_BNB_LC': '4', 'Y3_BNB_BLOCKS': '64',
+                                'Y3_X3_OVERFLOW': '0', 'Y3_KORDER': '0', 'Y3_X3_MODE': '0'}) == base
     assert _run(exe, [8, 416], {'Y3_NO_FAST': '1'}) != base      # the one switch the product reads (generic kernel everywhere)
 
 
@@ -108,6 +109,8 @@ DEV_ENVS = [
     {'Y3_X3_BN': '64', 'Y3_X3_KS': '16'},
     {'Y3_WGX3_WGS': '1500'},
     {'Y3_WGX3_WGS': '100'},
+    {'Y3_X3_OVERFLOW': '0'},
+    {'Y3_KORDER': '0'},
 ]
 
 
