@@ -117,7 +117,8 @@ int y3_conv2d_dgrad_x3_ok(const y3_tensor* ddst, int ksize, int stride, const y3
 /* Diagnostics (host only, no launch): the plan y3_conv2d_fwd and the stride-1 y3_conv2d_dgrad use for an implicit GEMM of
  * m x cout x (ksize^2 * cin).  out13 = {bm, bn, bk, tiles, f, s0, s1, chunk0, chunk1, grid, stats_tiles, fast, nk}: tiles
  * [0, f) are cut into s0 K slices of chunk0 K steps, tiles [f, tiles) into s1 of chunk1 (nk K steps in all); grid = work
- * items = workgroups.  Returns the workspace bytes (= y3_conv2d_fwd_workspace).  tests/planner_sweep.cpp replays the
+ * items = workgroups; fast: bit 0 = the MFMA kernel with split-K takes the launch, bit 1 = x3 plan whose short last slices are
+ * dealt to the blocks dispatched last (a few blocks more than workgroup slots).  Returns the workspace bytes (= y3_conv2d_fwd_workspace).  tests/planner_sweep.cpp replays the
  * kernel's item -> (tile, slice, slab, ticket) mapping from these numbers under AddressSanitizer. */
 size_t y3_conv2d_plan(int m, int cin, int ksize, int cout, int* out13);
 size_t y3_conv2d_plan_x(int m, int cin, int ksize, int cout, unsigned flags, int* out13);     /* the plan of a launch with `flags` (Y3_CONV_X3) */

@@ -1010,6 +1010,7 @@ struct ConvPlan {
     int f, s0, s1, chunk0, chunk1;   // FastArgs::sk_*: tiles [0,f) in s0 slices of chunk0 K steps, the rest in s1 of chunk1
     int tiles, stats_tiles;
     size_t ws_bytes;
+    int short_last = 0;              // x3 overflow plan: deal the short last slices to the blocks the dispatcher starts last (FastArgs::x3_mode bit 3)
 };
 // The K loop of conv_fast_body runs its steps in pairs (an odd count is padded with a dead step): slices get an even step count.
 static inline int even_steps(int chunk) { return chunk + (chunk & 1); }
@@ -1081,19 +1082,19 @@ static ConvPlan plan_conv_x3(int M, int Nout, int K, int ntaps) {
             pl.s0 = pl.s1 = s_lo;
             pl.chunk0 = pl.chunk1 = c_lo;
         }
-        // Overflow by SHORT slices: when the next larger count leaves a last slice of at most a third of the others and the launch
-        // has a multiple of 8 column tiles, every XCD's run of items (K-slice-major within a column: conv_fast_decode<KZMAJOR>) ENDS
-        // with those short slices, so the few blocks beyond the slots are short ones that start as the first short ones finish --
-        // and no tile needs the longer slices of s_lo (13x13 forward: 88 x 6 = 528 pieces of 54 / 18 steps instead of 80 x 6 + 8 x 4
-        // with 72-step pieces: 92 -> 82 us).
+        // Overflow by SHORT slices: when the next larger count leaves a last slice of at most a third of the others, every tile
+        // takes that count although the launch then has a few blocks more than slots: the items are dealt so that every XCD's
+        // blocks END with short slices (conv_fast_decode<SHORTLAST>), i.e. the blocks beyond the slots are short ones that start as
+        // the first short ones finish -- and no tile needs the longer slices of s_lo (13x13 forward: 88 x 6 = 528 pieces of 54 / 18
+        // steps instead of 80 x 6 + 8 x 4 with 72-step pieces: 92 -> 82 us).
         static const int overflow_on = env_int("Y3_X3_OVERFLOW", 1);
-        const int nbn = y3_cdiv(Nout, pl.t.bn);
-        if (c_hi > 0 && overflow_on && !force_ks && ntaps == 9 && nbn % 8 == 0) {
+        if (c_hi > 0 && overflow_on && !force_ks && ntaps == 9) {
             const int s_hi = count_for(c_hi), last = nk - (s_hi - 1) * c_hi;
             if ((long long)tiles * s_hi <= slots + slots / 16 && 3 * last <= c_hi) {
                 pl.f = tiles;
                 pl.s0 = pl.s1 = s_hi;
                 pl.chunk0 = pl.chunk1 = c_hi;
+                pl.short_last = 1;
                 c_hi = 0;
             }
         }
@@ -1232,7 +1233,7 @@ extern "C" size_t y3_conv2d_plan_x(int m, int cin, int ksize, int cout, unsigned
     const ConvPlan pl = plan_conv(m, cout, K, fast, x3, taps);
     if (out13) {
         const int v[13] = {pl.t.bm, pl.t.bn, pl.t.bk, pl.tiles, pl.f, pl.s0, pl.s1, pl.chunk0, pl.chunk1,
-                           pl.f * pl.s0 + (pl.tiles - pl.f) * pl.s1, pl.stats_tiles, fast ? 1 : 0, K / pl.t.bk};
+                           pl.f * pl.s0 + (pl.tiles - pl.f) * pl.s1, pl.stats_tiles, (fast ? 1 : 0) | (pl.short_last ? 2 : 0), K / pl.t.bk};
         for (int i = 0; i < 13; ++i) out13[i] = v[i];
     }
     return pl.ws_bytes;
@@ -1414,6 +1415,7 @@ static int launch_igemm(const ConvArgs& a, void* workspace, size_t workspace_byt
             return Y3_EINVAL;
         }
         if (x3) {
+            if (pl.short_last && pl.f == tiles) f.x3_mode |= 8;
             if (!y3_x3_launch(f, t.bm, t.bn, dense, grid, st)) {
                 y3_set_error("conv: no x3 kernel for tile %dx%d", t.bm, t.bn);
                 return Y3_EINVAL;

@@ -19,7 +19,7 @@ struct FastArgs {
     const float* src;  // biased so that every tap offset is >= 0
     const float* wt;   // [tap][C][Nout]; the x3 kernels (conv_x3.hip): the bf16 piece planes y3_x3_split_weights makes of the K-contiguous copy
     int Cper;          // channels per tap (K = ntaps * Cper)
-    int x3_mode;       // x3 kernels: bit 0 = non-temporal activation loads
+    int x3_mode;       // x3 kernels: bit 0 = non-temporal activation loads, bit 3 = short-last deal of the items (conv_fast_decode)
     // Order of the K steps of a multi-tap launch.  korder 2: 32-channel group (one 128-byte line per pixel) outermost, taps inside,
     // the two 16-channel halves of the line innermost: the taps of a group re-read the same few image rows, and so do the
     // neighbouring row tiles -- all within 2 * ntaps steps, while the rows are still in L2.  korder 0 (taps outermost) spaces the
@@ -157,8 +157,8 @@ struct FastWork {
 // KZMAJOR (the x3 patch kernel): with column-major tile ids the items of a column are dealt K slice by K slice (row tile fastest)
 // instead of tile by tile: the run of items an XCD takes then holds ALL row tiles of a few (column, K slice) pairs -- they load
 // the same weight blocks step by step, so a block of the planes is fetched into one L2 instead of two or three.  Only who
-// computes which item changes; item ids (slab slots, tickets) stay tile-major.
-template <int BM, int BN, int WM, int WN, int BK, bool KZMAJOR = false>
+// computes which item changes; item ids (slab slots, tickets) stay tile-major.  SHORTLAST (the x3 kernels): see below.
+template <int BM, int BN, int WM, int WN, int BK, bool KZMAJOR = false, bool SHORTLAST = false>
 __device__ __forceinline__ FastWork conv_fast_decode(const FastArgs& p, const int braw, const int grid) {
     FastWork w;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -181,7 +181,23 @@ __device__ __forceinline__ FastWork conv_fast_decode(const FastArgs& p, const in
 
     // work item: ids are contiguous per XCD inside the two ranges [0, sk_n0) and [sk_n0, grid)
     int bid0 = braw < sk_n0 ? y3_xcd_remap(braw, sk_n0) : sk_n0 + y3_xcd_remap(braw - sk_n0, grid - sk_n0);
-    if (KZMAJOR && col_major) {
+    if (SHORTLAST && (p.x3_mode & 8) && sk_n0 == grid && sk_s0 > 1) {
+        // SHORT-LAST deal (the planner's overflow plans: every tile in s slices, the last one short, a few blocks more than slots):
+        // an XCD takes its eighth of the LONG items (K-slice-major as below) first and fills up with SHORT ones, so the blocks the
+        // dispatcher starts last -- the ones beyond the slots -- are short everywhere
+        const int s = sk_s0, tiles = sk_f, nl = tiles * (s - 1);
+        const int x = braw & 7, j = braw >> 3;
+        const int ql = nl >> 3, rl = nl & 7;
+        const int nlx = ql + (x < rl ? 1 : 0), l0 = x * ql + min(x, rl);      // this XCD's share of the long items
+        if (j < nlx) {
+            const int a = l0 + j, col = a / (nb_fast * (s - 1)), r = a - col * nb_fast * (s - 1), kzp = r / nb_fast;
+            bid0 = (col * nb_fast + (r - kzp * nb_fast)) * s + kzp;
+        } else {
+            int s0x = 0;                                                      // short items the XCDs in front of this one take
+            for (int y = 0; y < x; ++y) s0x += ((grid - y + 7) >> 3) - (ql + (y < rl ? 1 : 0));
+            bid0 = (s0x + j - nlx) * s + (s - 1);
+        }
+    } else if (KZMAJOR && col_major) {
         const bool ra = bid0 < sk_n0;
         const int sl = ra ? sk_s0 : sk_s1;
         if (sl > 1) {

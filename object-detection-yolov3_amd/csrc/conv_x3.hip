@@ -70,7 +70,7 @@ __device__ __forceinline__ void conv_x3_body(const FastArgs& p, const int braw, 
         y3_timing_buf[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
-    const FastWork fw = conv_fast_decode<BM, BN, WM, WN, BK>(p, braw, grid);
+    const FastWork fw = conv_fast_decode<BM, BN, WM, WN, BK, false, true>(p, braw, grid);
     const int tid = fw.tid, l31 = fw.l31, lh = fw.lh, wm = fw.wm, wn = fw.wn;
     const int m0 = fw.m0, n0 = fw.n0, kbeg = fw.kbeg, kend = fw.kend;
     const int ohw = fw.ohw, OW = fw.OW, aM = fw.aM, aH = fw.aH, aW = fw.aW, src_ld = fw.src_ld, csh = fw.csh, csw = fw.csw, ntaps = fw.ntaps, Nout = fw.Nout;
@@ -398,7 +398,7 @@ __device__ __forceinline__ void conv_x3p_body(const FastArgs& p, const int braw,
         y3_timing_buf[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
-    const FastWork fw = conv_fast_decode<BM, BN, WM, WN, BK, true>(p, braw, grid);
+    const FastWork fw = conv_fast_decode<BM, BN, WM, WN, BK, true, true>(p, braw, grid);
     const int tid = fw.tid, l31 = fw.l31, lh = fw.lh, wm = fw.wm, wn = fw.wn;
     const int m0 = fw.m0, n0 = fw.n0, kbeg = fw.kbeg, kend = fw.kend;
     const int ohw = fw.ohw, OW = fw.OW, aM = fw.aM, aH = fw.aH, aW = fw.aW, src_ld = fw.src_ld, Nout = fw.Nout;

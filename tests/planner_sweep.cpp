@@ -58,7 +58,7 @@ static void check_conv_plan(const char* what, int m, int cin, int k, int cout, u
     REQUIRE(tiles == cdiv(m, bm) * cdiv(cout, bn) && stats_tiles == cdiv(m, bm), "%s: tile count", what);
     REQUIRE(f >= 0 && f <= tiles && s0 >= 1 && s1 >= 1 && c0 >= 1 && c1 >= 1, "%s: split parameters", what);
     REQUIRE((long long)f * s0 + (long long)(tiles - f) * s1 == grid && grid > 0, "%s: grid", what);
-    if (!fast) {
+    if (!(fast & 1)) {
         REQUIRE(s0 == 1 && s1 == 1 && ws == 0, "%s: the generic kernel has no split-K", what);
         return;
     }
@@ -78,7 +78,20 @@ static void check_conv_plan(const char* what, int m, int cin, int k, int cout, u
     std::vector<unsigned char> seen((size_t)grid, 0), slices((size_t)tiles, 0);
     for (int b = 0; b < grid; ++b) {
         int item = b < n0 ? xcd_remap(b, n0) : n0 + xcd_remap(b - n0, grid - n0);
-        if ((flags & Y3_CONV_X3) && k == 3) {
+        if ((flags & Y3_CONV_X3) && (fast & 2) && n0 == grid && s0 > 1) {
+            // conv_fast_decode<SHORTLAST>: an XCD takes its eighth of the long items first and fills up with short ones
+            const int nb = cdiv(m, bm), nl = tiles * (s0 - 1), x = b & 7, j = b >> 3, ql = nl >> 3, rl = nl & 7;
+            const int nlx = ql + (x < rl ? 1 : 0), l0 = x * ql + std::min(x, rl);
+            if (j < nlx) {
+                const int a = l0 + j, col = a / (nb * (s0 - 1)), r = a - col * nb * (s0 - 1), kzp = r / nb;
+                item = (col * nb + (r - kzp * nb)) * s0 + kzp;
+            } else {
+                int s0x = 0;
+                for (int y = 0; y < x; ++y) s0x += ((grid - y + 7) >> 3) - (ql + (y < rl ? 1 : 0));
+                REQUIRE(s0x + j - nlx >= 0 && s0x + j - nlx < tiles, "%s: short item %d of %d (block %d)", what, s0x + j - nlx, tiles, b);
+                item = (s0x + j - nlx) * s0 + (s0 - 1);
+            }
+        } else if ((flags & Y3_CONV_X3) && k == 3) {
             // conv_fast_decode<KZMAJOR> (x3 patch kernel, column-major tile ids): the items of a column are dealt K slice by K slice
             const bool ra = item < n0;
             const int sl = ra ? s0 : s1, nb = cdiv(m, bm);
