@@ -1967,6 +1967,9 @@ static WgradPlan plan_wgrad_x3(int K, int Nout, int M) {
     static const int want = env_int("Y3_WGX3_WGS", 480);
     int splits = want / w.tiles;
     if (splits < 1) splits = 1;
+    // more tiles than CUs (13x13 3x3 layers: 288): one pixel run per tile leaves most CUs with a lone workgroup; two runs are a
+    // round and an eighth; three (864 workgroups of ~28 steps, reduced in the kernel) measured best: 98 -> 87 us
+    if (w.tiles > 256 && splits < 3) splits = 3;
     const int maxs = y3_cdiv(M, 192);
     if (splits > maxs) splits = maxs;
     if (splits < y3_cdiv(M, Y3_WG_TABLE - 96)) splits = y3_cdiv(M, Y3_WG_TABLE - 96);       // a split's pixels fit the LDS pixel table
