@@ -743,14 +743,14 @@ class YoloV3:
             return False
         if self.conv_arithmetic == 'x3-all':
             return True
-        # measured (tools/x3_check.py, batch 8 at 416^2, launch by launch and inside the step): the 3x3 layers gain -- forward
-        # 1.2-1.7x from 64 input channels up and on every stride-2 layer, stride-1 data gradients 1.3-1.5x with >= 128 contracted
-        # channels; the 1x1 layers (4-64 K steps: prologue + epilogue bound) and the 32-channel layers do not
+        # measured (tools/x3_check.py --all, tools/layer_times.py; batch 8 at 416^2, launch by launch and inside the step): the 3x3
+        # layers gain -- forward 1.2-1.8x, stride-1 data gradients 1.1-1.7x with >= 128 contracted channels and >= 64 outputs
+        # (0.79x for the 64 -> 32 one); the 1x1 layers (4-64 K steps: prologue + epilogue bound) do not
         if ntaps != 9:
             return False
         if forward:
-            return c >= 64 or stride == 2
-        return c >= 128 and nout >= 128
+            return True          # every 3x3 layer the kernels take (>= 32 input channels): 208^2 32->64 140 -> 116 us, the others 1.5-1.8x
+        return c >= 128 and nout >= 64
 
     def x3_forward(self, sp, m_out):
         return self._x3_policy(sp.cin_pad, sp.k * sp.k, sp.cout, m_out, sp.s, True)
