@@ -345,6 +345,8 @@ DGRAD_CASES = [
     (1, 13, 15, 32, 64, 3, 2),
     (2, 13, 13, 256, 14, 1, 1),
     (2, 64, 64, 64, 128, 3, 2),
+    (1, 27, 31, 64, 64, 3, 2),      # odd sizes: the four parity classes have different pixel counts; 64-column tiles of the x3 merged launch
+    (3, 30, 26, 128, 256, 3, 2),    # x3 merged launch with per-class K slices, row tiles not full
 ]
 
 
@@ -390,7 +392,7 @@ def test_conv_dgrad(hip, case, accum, arith):
 
 
 @pytest.mark.parametrize('shape', [(8, 13, 13, 512, 1024, 3), (8, 26, 26, 128, 256, 1), (2, 52, 52, 64, 128, 3), (8, 52, 52, 128, 256, 3), (1, 13, 15, 64, 32, 1),
-                                   (2, 104, 104, 64, 128, 3, 2), (8, 26, 26, 256, 512, 3, 2), (1, 30, 26, 32, 64, 3, 2)])
+                                   (2, 104, 104, 64, 128, 3, 2), (8, 26, 26, 256, 512, 3, 2), (1, 30, 26, 32, 64, 3, 2), (2, 27, 31, 128, 128, 3, 2)])
 @pytest.mark.parametrize('arith', ['f32', 'x3'])
 @pytest.mark.parametrize('accum', [False, True])
 def test_conv_dgrad_bn_epilogue_stats(hip, shape, accum, arith):
