@@ -1063,7 +1063,7 @@ static ConvPlan plan_conv_x3(int M, int Nout, int K, int ntaps) {
     } else if (tiles <= Y3_MAX_TICKETS && tiles <= 256) {
         // Fewer tiles than CUs: cut along K so that the launch fills the chip's workgroup slots ONCE, two per CU -- a lone workgroup
         // (one wave per SIMD) runs its loop at a third of the MFMA rate, and a second, partly filled round costs a whole round
-        // (measured, tools/probe/x3_sweep5/9.sh: 507 pieces 78 us, 338 pieces 97 us, 676 pieces 103 us on the same launch).
+        // (measured, tools/probe/x3_ks_sweep.sh / x3_ks_sweep2.sh: 507 pieces 78 us, 338 pieces 97 us, 676 pieces 103 us on the same launch).
         // The slice counts a launch can have are ceil(nk / c) for c a multiple of the unit; take the largest count s_lo with
         // tiles * s_lo <= slots and give the next larger one, s_hi, to as many tiles as fill the rest of the slots.
         auto count_for = [&](int c) { return y3_cdiv(nk, c); };

@@ -1,3 +1,4 @@
+# development: bench.py under Y3_KORDER 0 / 1 / 2 on one box (K order of the multi-tap launches)
 export PYTHONPATH=object-detection-yolov3_amd
 export Y3_LIB=object-detection-yolov3_amd/yolo3/_lib/libyolo3hip_dev.so
 for ko in 2 0 1 2 0; do

@@ -1,3 +1,4 @@
+# development: forced K slice counts (Y3_X3_KS) over the three 3x3 shapes
 export PYTHONPATH=object-detection-yolov3_amd
 export Y3_LIB=object-detection-yolov3_amd/yolo3/_lib/libyolo3hip_dev.so
 L=gpurun_out/r04_x3_ks2.log

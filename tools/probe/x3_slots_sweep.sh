@@ -1,3 +1,4 @@
+# development: workgroup slots a launch fills (Y3_X3_SLOTS 512 / 768) + conv tests + bench
 export PYTHONPATH=object-detection-yolov3_amd
 L=gpurun_out/r04_x3_slots.log
 : > $L

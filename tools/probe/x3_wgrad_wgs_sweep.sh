@@ -1,3 +1,4 @@
+# development: workgroups an x3 kernel gradient aims at (Y3_WGX3_WGS)
 export PYTHONPATH=object-detection-yolov3_amd
 export Y3_LIB=object-detection-yolov3_amd/yolo3/_lib/libyolo3hip_dev.so
 L=gpurun_out/r04_wgx3_wgs.log
