@@ -65,6 +65,12 @@ int y3_x3_split_weights(const float* w, void* planes, int taps, int rows, int k_
  * layer's kernel (floats), taps, rows, k_per_row, index of the layer's first block}, blocks of 1024 elements; total_blocks = sum over
  * layers of ceil(taps * rows * k_per_row / 1024).  The planes of a layer are written at planes_arena + 3 * offset (bf16 elements). */
 int y3_x3_split_weights_batched(const float* arena, void* planes_arena, const int* table_dev, int nlayers, int total_blocks, y3_stream_t stream);
+/* y3_transpose_weights_batched and the two y3_x3_split_weights_batched launches of an optimiser step in ONE pass over the arena:
+ * params_t <- the transposed kernels, planes <- piece planes of the Keras copy, planes_t <- piece planes of the transposed copy
+ * (each for the layers whose K per row is a multiple of 16; layouts as above, a layer's planes at 3 x its arena offset).
+ * table_dev / nlayers / total_tiles: as for y3_transpose_weights_batched.  Bit-identical to the three launches it replaces. */
+int y3_x3_prepare_weights_batched(const float* params, float* params_t, void* planes, void* planes_t, const int* table_dev, int nlayers,
+                                  int total_tiles, y3_stream_t stream);
 
 /*
  * Tensor view: NHWC, `ld` floats between consecutive pixels.

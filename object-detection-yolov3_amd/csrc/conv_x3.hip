@@ -1086,6 +1086,74 @@ extern "C" int y3_x3_split_weights_batched(const float* arena, void* planes_aren
     return Y3_OK;
 }
 
+// Everything the optimiser step leaves to refresh, in ONE pass over the parameter arena: the transposed fp32 copy (operand of the
+// fp32 data gradients, y3_transpose_weights_batched's job) and the piece planes of both copies (the two y3_x3_split_weights_batched
+// launches) -- the arena is read once instead of three times and the transposed copy is not read back.  A block owns one 32 x 32
+// (Cin x Cout) tile of one tap of one layer; table[l] = {arena offset, taps, cin, cout, first tile} as for the transpose.  The
+// planes of a copy are written for the layers whose K per row is a multiple of 16 (the x3 kernels take no others).
+__device__ __forceinline__ void x3_split4(f32x4 r, unsigned short* d) {      // d: piece 0 of the four k; pieces 1, 2 follow 16 and 32 bf16 further
+    const unsigned a0 = x3_pk(r[0], r[1]), a1 = x3_pk(r[2], r[3]);
+    r[0] -= x3_lo(a0); r[1] -= x3_hi(a0); r[2] -= x3_lo(a1); r[3] -= x3_hi(a1);
+    const unsigned b0 = x3_pk(r[0], r[1]), b1 = x3_pk(r[2], r[3]);
+    r[0] -= x3_lo(b0); r[1] -= x3_hi(b0); r[2] -= x3_lo(b1); r[3] -= x3_hi(b1);
+    *reinterpret_cast<uint2*>(d) = make_uint2(a0, a1);
+    *reinterpret_cast<uint2*>(d + 16) = make_uint2(b0, b1);
+    *reinterpret_cast<uint2*>(d + 32) = make_uint2(x3_pk(r[0], r[1]), x3_pk(r[2], r[3]));
+}
+__global__ __launch_bounds__(256) void x3_prepare_weights_kernel(const float* __restrict__ params, float* __restrict__ params_t, unsigned short* __restrict__ planes,
+                                                                 unsigned short* __restrict__ planes_t, const int* __restrict__ table, int nlayers) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = nlayers - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 5 + 4] <= (int)blockIdx.x)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const long long off = table[lo * 5];
+    const int cin = table[lo * 5 + 2], cout = table[lo * 5 + 3];
+    const int local = blockIdx.x - table[lo * 5 + 4];
+    const int tco = (cout + 31) >> 5, tci = (cin + 31) >> 5;
+    const int t = local / (tco * tci), rem = local % (tco * tci);
+    const int ci0 = (rem / tco) * 32, co0 = (rem % tco) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = params + off + (long long)t * cin * cout;
+    float* dst = params_t + off + (long long)t * cin * cout;
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        tile[r][tx] = (ci < cin && co < cout) ? src[(long long)ci * cout + co] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        if (ci < cin && co < cout) dst[(long long)co * cin + ci] = tile[tx][r];
+    }
+    const int row = threadIdx.x >> 3, q = (threadIdx.x & 7) * 4;
+    if ((cout & 15) == 0) {      // planes of the Keras copy [tap][Cin][Cout]: row = input channel, k = output channel
+        const int ci = ci0 + row, co = co0 + q;
+        if (ci < cin && co < cout) {
+            const f32x4 v = {tile[row][q], tile[row][q + 1], tile[row][q + 2], tile[row][q + 3]};
+            x3_split4(v, planes + 3 * off + ((((long long)t * (cout >> 4) + (co >> 4)) * cin + ci) * 3) * 16 + (co & 15));
+        }
+    }
+    if ((cin & 15) == 0) {       // planes of the transposed copy [tap][Cout][Cin]: row = output channel, k = input channel
+        const int co = co0 + row, ci = ci0 + q;
+        if (co < cout && ci < cin) {
+            const f32x4 v = {tile[q][row], tile[q + 1][row], tile[q + 2][row], tile[q + 3][row]};
+            x3_split4(v, planes_t + 3 * off + ((((long long)t * (cin >> 4) + (ci >> 4)) * cout + co) * 3) * 16 + (ci & 15));
+        }
+    }
+}
+extern "C" int y3_x3_prepare_weights_batched(const float* params, float* params_t, void* planes, void* planes_t, const int* table_dev, int nlayers,
+                                             int total_tiles, y3_stream_t stream) {
+    Y3_CHECK_ARG(params && params_t && planes && planes_t && table_dev && nlayers > 0 && total_tiles > 0, "x3_prepare_weights_batched: bad args");
+    hipLaunchKernelGGL(x3_prepare_weights_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, params, params_t, (unsigned short*)planes,
+                       (unsigned short*)planes_t, table_dev, nlayers);
+    Y3_CHECK_LAUNCH("x3_prepare_weights_batched");
+    return Y3_OK;
+}
+
 // Tiles this file is built for (conv.hip plans with them): false if (bm, bn) is not one of them.
 bool y3_x3_tile_ok(int bm, int bn) { return bm == 128 && (bn == 128 || bn == 64); }
 

@@ -51,6 +51,7 @@ SIGNATURES = {
     'y3_conv2d_dgrad_x3_ok': (i32, [TP, i32, i32, TP]),
     'y3_x3_split_weights': (i32, [fp, vp, i32, i32, i32, vp]),
     'y3_x3_split_weights_batched': (i32, [fp, vp, ip, i32, i32, vp]),
+    'y3_x3_prepare_weights_batched': (i32, [fp, fp, vp, vp, ip, i32, i32, vp]),
     'y3_conv2d_dgrad_workspace_x': (sz, [TP, i32, i32, TP, u32]),
     'y3_conv2d_dgrad_bn_tiles_x': (i32, [TP, i32, i32, TP, u32]),
     'y3_conv2d_dgrad_workspace': (sz, [TP, i32, i32, TP]),

@@ -891,6 +891,12 @@ class YoloV3:
                 start += sp.k * sp.k * (-(-sp.cin_pad // 32)) * (-(-sp.cout // 32))
             self._tr_table = torch.tensor(rows, dtype=torch.int32, device=self.device)
             self._tr_tiles = start
+        if self.planes is not None and os.environ.get('Y3_PREP_FUSED', '1') != '0':
+            # one pass over the arena: transposed copy + the piece planes of both copies (bit-identical to the three launches below)
+            check(lib.y3_x3_prepare_weights_batched(self.params.data_ptr(), self.params_t.data_ptr(), self.planes.data_ptr(), self.planes_t.data_ptr(),
+                                                    self._tr_table.data_ptr(), len(self.specs) - 1, self._tr_tiles, self._stream()), 'y3_x3_prepare_weights_batched')
+            self._bf16_stale = True
+            return
         check(lib.y3_transpose_weights_batched(self.params.data_ptr(), self.params_t.data_ptr(), self._tr_table.data_ptr(), len(self.specs) - 1,
                                                self._tr_tiles, self._stream()), 'y3_transpose_weights_batched')
         if self.planes is not None:

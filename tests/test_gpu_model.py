@@ -69,6 +69,24 @@ def _setup(img, n, seed, randomize_bn, conv_arithmetic=None):
     return om, params, yolo, images, gts
 
 
+def test_weight_preparation_in_one_pass_equals_the_three_launches(monkeypatch):
+    """y3_x3_prepare_weights_batched (transposed copy + piece planes of both copies in one pass over the arena) writes, bit for bit,
+    what y3_transpose_weights_batched and the two y3_x3_split_weights_batched launches write."""
+    om, params, yolo, _, _ = _setup(64, 1, 5, True)
+    assert yolo.planes is not None
+    outs = []
+    for fused in ('0', '1'):
+        monkeypatch.setenv('Y3_PREP_FUSED', fused)
+        for t in (yolo.params_t, yolo.planes, yolo.planes_t):
+            t.zero_()
+        yolo._refresh_transposed()
+        torch.cuda.synchronize()
+        outs.append([yolo.params_t.clone(), yolo.planes.view(torch.int16).clone(), yolo.planes_t.view(torch.int16).clone()])
+    for a, b, name in zip(outs[0], outs[1], ('params_t', 'planes', 'planes_t')):
+        assert torch.equal(a, b), name
+    assert int((outs[1][1] != 0).sum()) > 1000000 and int((outs[1][2] != 0).sum()) > 1000000
+
+
 def test_set_get_weights_roundtrip():
     om, params, yolo, _, _ = _setup(64, 1, 3, True)
     back = yolo.get_weights()
