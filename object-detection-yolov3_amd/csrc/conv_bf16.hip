@@ -896,6 +896,243 @@ __global__ __launch_bounds__(256) void conv_first_bf16_mfma_kernel(const float* 
 }
 
 // ---------------------------------------------------------------------------
+// 3x3, Cin = 32 -> Cout = 64, stride 1 or 2: the 608^2 -> 304^2 stage of the tiled path, as a PATCH kernel.
+//
+// Why another kernel: as im2col rows of conv_bf16_kernel<128, 64> these two layers read
+// every input pixel nine times through L2 -> LDS and ran 3-4 x above their HBM time (464 / 419 us for 45 tiles of 608^2 where
+// the activations need 100-170 us).  Here a workgroup (4 waves) walks DOWN a strip of 32 output columns in groups of RPG
+// output rows; the input patch of a group ((RPG-1) S + 3 rows x 31 S + 3 pixels x 32 channels = 64 B per pixel) is loaded
+// ONCE into LDS -- the next group's patch is in flight in registers under the current group's MFMAs, two LDS buffers, one
+// barrier per group -- and the nine taps are walked from LDS.  D = [channel][pixel] as in conv_bf16_pp_kernel: the weights are
+// the MFMA's A operand and stay in REGISTERS for the whole launch (wave = one 32-channel block: 9 taps x 2 K halves = 18
+// fragments = 72 VGPRs), the pixels its B operand: one ds_read_b128 per (patch row, kx, K half), used by every output row
+// of the wave that sees this patch row through some ky (stride 1: up to three rows -> 36 reads for 72 MFMAs).
+// Waves: (channel block cb = wave & 1) x (row set rs = wave >> 1, RW = RPG / 2 output rows each).
+// LDS pixel layout: [row][plane][idx][4 slots of 16 B], slot ^= (idx >> 2) & 3.  Stride 1: one plane, idx = column; stride 2:
+// even and odd input columns in two planes (idx = column / 2), so that the 32 pixels of a fragment read (columns 2 l + kx)
+// are CONSECUTIVE idx and the reads are conflict-free for both strides; the plane pitch (34 pixels) puts the odd plane 128 B
+// off in bank space, so the stores (4 slots x 4 neighbouring pixels per 16 lanes) are conflict-free too.
+// The launch is persistent: min(groups, 2 per CU) workgroups take contiguous runs of the (image, strip, row group) list.
+// Epilogue from registers: bias -> leaky-relu -> folded BN affine (constants parked in LDS) -> v_permlane32_swap to 8-channel
+// runs -> + residual (16-byte loads) -> ONE rounding -> 16-byte stores.
+// ---------------------------------------------------------------------------
+struct PatchArgs {
+    const u16* src;
+    const u16* wt;
+    u16* dst;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    const u16* resid;
+    unsigned src_bytes, dst_bytes, resid_bytes;   // resid_bytes 0: no residual (every access out of range = 0)
+    int H, W, OH, OW, src_ld, dst_ld, resid_ld;
+    int pbh, pbw;            // SAME padding before (rows, columns)
+    int xs, rg, groups;      // strips per image row, row groups per strip, groups in the launch (images x xs x rg)
+    Y3Div dv_rg, dv_xs;
+    unsigned flags;
+    float alpha;
+};
+
+template <int S>
+__global__ __launch_bounds__(256, 2) void conv_bf16_c32_kernel(const PatchArgs p) {
+    constexpr int RPG = S == 1 ? 8 : 4, RW = RPG / 2;          // output rows per group / per wave
+    constexpr int IR = (RPG - 1) * S + 3, IC = 31 * S + 3;      // patch rows / columns
+    constexpr int PLANEB = 34 * 64;
+    constexpr int ROWB = S * PLANEB, BUFB = IR * ROWB;
+    constexpr int QUADS = IR * IC * 4, NL = (QUADS + 255) / 256;
+    constexpr int PL = (RW - 1) * S + 3;                        // patch rows one wave reads
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFB + 3 * 64 * 4];
+    float* epi = reinterpret_cast<float*>(smem + 2 * BUFB);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int cb = wave & 1, rs = wave >> 1;
+    const int g_begin = (int)((long long)blockIdx.x * p.groups / gridDim.x), g_end = (int)((long long)(blockIdx.x + 1) * p.groups / gridDim.x);
+    if (g_begin >= g_end) return;
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.src), 0, p.src_bytes, 0x00020000);
+    const int aH = p.H, aW = p.W, src_ld = p.src_ld;
+
+    // the quads this thread stages: q = tid + 256 i -> (patch row, column, 16-byte slot); recomputed where needed (a few integer
+    // operations with constant divisors) rather than kept in 3 NL registers beside 72 of weights and 64 of accumulators
+    auto quad = [&](int t, int i, int& row, int& px, int& slot) {
+        const int q = t + 256 * i;
+        row = q / (IC * 4);
+        const int rem = q - row * (IC * 4);
+        px = rem >> 2;
+        slot = rem & 3;
+    };
+    auto decode = [&](int g, int& img, int& oy0, int& ox0) {
+        const int t = y3_div(g, p.dv_rg), rgi = g - t * p.rg;
+        img = y3_div(t, p.dv_xs);
+        oy0 = rgi * RPG;
+        ox0 = (t - img * p.xs) * 32;
+    };
+    f32x4 nxt[NL];
+    // every memory operation of the loop is UNCONDITIONAL (out-of-range offsets instead of branches): the compiler's vmcnt
+    // bookkeeping is then exact and a wait for one load does not degrade to vmcnt(0), which would end the prefetch early
+    auto gload = [&](int g, bool live) {
+        int img, oy0, ox0;
+        decode(g, img, oy0, ox0);
+        const int iy0 = oy0 * S - p.pbh, ix0 = ox0 * S - p.pbw;
+        const int base = ((img * aH + iy0) * aW + ix0) * src_ld * 2;   // may be negative; with the quad's own offset it is not, for a pixel inside the image
+        int t = tid;
+        asm volatile("" : "+v"(t));              // opaque: otherwise the quad decode is hoisted out of the group loop into 3 NL registers
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            int row, px, slot;
+            quad(t, i, row, px, slot);
+            const int iy = iy0 + row, ix = ix0 + px;
+            const bool ok = live & (row < IR) & ((unsigned)iy < (unsigned)aH) & ((unsigned)ix < (unsigned)aW);   // & not &&: no branches
+            nxt[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, ok ? (unsigned)(base + ((row * aW + px) * src_ld + slot * 8) * 2) : Y3_OOB, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            int row, px, slot;
+            quad(t, i, row, px, slot);
+            const int idx = S == 1 ? px : px >> 1, plane = S == 1 ? 0 : px & 1;
+            if (i + 1 < NL || row < IR)
+                *reinterpret_cast<f32x4*>(smem + buf * BUFB + row * ROWB + plane * PLANEB + idx * 64 + ((slot ^ ((idx >> 2) & 3)) << 4)) = nxt[i];
+        }
+    };
+    gload(g_begin, true);
+
+    // weights: A operand, lane = (channel cb * 32 + l31, k = lh * 8 .. + 7 of the 16-channel half kh)
+    bf16x8 wf[3][3][2];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+                wf[ky][kx][kh] = *reinterpret_cast<const bf16x8*>(p.wt + ((ky * 3 + kx) * 64 + cb * 32 + l31) * 32 + kh * 16 + lh * 8);
+    if (tid < 64) {
+        epi[tid] = p.bias ? p.bias[tid] : 0.f;
+        epi[64 + tid] = p.scale ? p.scale[tid] : 1.f;
+        epi[128 + tid] = p.scale ? p.shift[tid] : 0.f;
+    }
+    // fragment reads: pixel column l31 * S + kx of patch row rs * 4 + pl, slot kh * 2 + lh
+    int b_addr[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const int idx = S == 1 ? l31 + kx : l31 + (kx >> 1), plane = S == 1 ? 0 : kx & 1, slot = kh * 2 + lh;
+            b_addr[kx][kh] = rs * 4 * ROWB + plane * PLANEB + idx * 64 + ((slot ^ ((idx >> 2) & 3)) << 4);
+        }
+    const bool do_lrelu = p.flags & Y3_EPI_LRELU;
+    const bool has_scale = p.scale != nullptr;
+    const float alpha = p.alpha;
+    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.resid ? p.resid : p.src), 0, p.resid_bytes, 0x00020000);
+    const int aOH = p.OH, aOW = p.OW, dst_ld = p.dst_ld, resid_ld = p.resid_ld;
+
+    lstore(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the weights have landed -- no wait for them inside the loop
+    __syncthreads();
+    int buf = 0;
+#pragma unroll 1
+    for (int g = g_begin; g < g_end; ++g, buf ^= 1) {
+        const bool more = g + 1 < g_end;
+        gload(g + 1, more);                      // in flight under this group's MFMAs and stores
+        __builtin_amdgcn_sched_barrier(0);
+        int img, oy0, ox0;
+        decode(g, img, oy0, ox0);
+        f32x16 acc[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+        const unsigned char* bb = smem + buf * BUFB;
+        // the six fragments of patch row pl + 1 are read while the MFMAs of patch row pl issue (two register sets; the
+        // sched_barrier keeps the compiler from hoisting ALL 6 PL reads to the top, which costs 100+ VGPRs and spills)
+        bf16x8 bf[2][3][2];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) bf[0][kx][kh] = *reinterpret_cast<const bf16x8*>(bb + b_addr[kx][kh]);
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) {
+            if (pl + 1 < PL) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int kh = 0; kh < 2; ++kh) bf[(pl + 1) & 1][kx][kh] = *reinterpret_cast<const bf16x8*>(bb + b_addr[kx][kh] + (pl + 1) * ROWB);
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) {
+                        const int ky = pl - r * S;
+                        if (ky >= 0 && ky < 3) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ky][kx][kh], bf[pl & 1][kx][kh], acc[r], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // epilogue: acc[r][4 g + j] = channel cb * 32 + 8 g + 4 lh + j of pixel (oy0 + rs * RW + r, ox0 + l31).  The residual of
+        // ALL rows is requested first (the fragment registers are free now): one exposed round trip per group, not one per store
+        const int ox = ox0 + l31;
+        unsigned o_dst[RW];
+        f32x4 rv[RW][2];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int oy = oy0 + rs * RW + r;
+            const bool valid = oy < aOH && ox < aOW;
+            const int m = (img * aOH + oy) * aOW + ox;
+            o_dst[r] = valid ? (unsigned)(m * dst_ld + cb * 32 + 8 * lh) * 2u : Y3_OOB;
+            const unsigned o_res = valid ? (unsigned)(m * resid_ld + cb * 32 + 8 * lh) * 2u : Y3_OOB;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) rv[r][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, o_res, e * 32, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            float v[16];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int c = cb * 32 + 8 * gq + 4 * lh;           // the constants are re-read per row (broadcast reads): 48 registers otherwise
+                const f32x4 eb = *reinterpret_cast<const f32x4*>(epi + c), es = *reinterpret_cast<const f32x4*>(epi + 64 + c),
+                            ef = *reinterpret_cast<const f32x4*>(epi + 128 + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = acc[r][4 * gq + j] + eb[j];
+                    if (do_lrelu) x = x > 0.f ? x : alpha * x;
+                    if (has_scale) x = x * es[j] + ef[j];
+                    v[4 * gq + j] = x;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Y3_SWAP32(v[8 * e + j], v[8 * e + 4 + j]);
+                // lanes < 32 now hold channels cb * 32 + 16 e .. + 7 of their pixel, lanes >= 32 channels + 8 .. + 15
+                float* w = v + 8 * e;
+                const f32x4 rr = rv[r][e];
+                unsigned pk[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned rw = __float_as_uint(rr[q]);
+                    const float lo = w[2 * q] + __uint_as_float(rw << 16), hi = w[2 * q + 1] + __uint_as_float(rw & 0xffff0000u);
+                    pk[q] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(f32x4{__uint_as_float(pk[0]), __uint_as_float(pk[1]), __uint_as_float(pk[2]), __uint_as_float(pk[3])},
+                                                       rs_dst, o_dst[r], e * 32, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) {
+            lstore(buf ^ 1);                     // the other buffer was last read one iteration ago, before the barrier below
+            y3_lds_barrier();                    // LDS only: the epilogue's stores stay in flight across it
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // small bf16 helpers
 // ---------------------------------------------------------------------------
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, size_t count) {
@@ -1123,6 +1360,47 @@ static int conv2d_fwd_bf16_impl(const y3_tensor* src, const void* wt_t_bf16, con
         p.dv_ow = y3_make_div(p.OW);
         hipLaunchKernelGGL(conv_bf16_pp_kernel, dim3((unsigned)tpp), dim3(512), 0, st, p);
         Y3_CHECK_LAUNCH("conv_bf16_pp");
+        return Y3_OK;
+    }
+    // the patch kernel for the 32 -> 64 3x3 layers (conv_bf16_c32_kernel)
+    static const int patch_on = dev_int("Y3_BF16_PATCH", 1);   // 0 = off (A/B against conv_bf16_kernel<128, 64>)
+    if (patch_on && ksize == 3 && p.C == 32 && p.Nout == 64 && !dst_is_f32 && p.vec_ok && ((uintptr_t)wt_t_bf16 & 15) == 0 &&
+        (!bias || ((uintptr_t)bias & 3) == 0) && src->h < 0x4000 && src->w < 0x4000) {
+        PatchArgs q = {};
+        q.src = (const u16*)src->ptr;
+        q.wt = (const u16*)wt_t_bf16;
+        q.dst = (u16*)dst->ptr;
+        q.bias = bias;
+        q.scale = scale;
+        q.shift = shift;
+        q.resid = p.resid;
+        q.src_bytes = (unsigned)((long long)src->n * src->h * src->w * src->ld * 2);
+        q.dst_bytes = p.dst_bytes;
+        q.resid_bytes = p.resid ? p.resid_bytes : 0u;
+        q.H = src->h;
+        q.W = src->w;
+        q.OH = OH;
+        q.OW = OW;
+        q.src_ld = src->ld;
+        q.dst_ld = dst->ld;
+        q.resid_ld = p.resid_ld;
+        q.pbh = pbh;
+        q.pbw = pbw;
+        q.xs = y3_cdiv(OW, 32);
+        q.rg = y3_cdiv(OH, stride == 1 ? 8 : 4);
+        const long long groups = (long long)src->n * q.xs * q.rg;
+        Y3_CHECK_ARG(groups < 0x7fffffffLL, "conv2d_fwd_bf16: too many row groups");
+        q.groups = (int)groups;
+        q.dv_rg = y3_make_div(q.rg);
+        q.dv_xs = y3_make_div(q.xs);
+        q.flags = flags;
+        q.alpha = alpha;
+        const unsigned grid = (unsigned)(groups < 512 ? groups : 512);       // two workgroups per CU, each a contiguous run of groups
+        if (stride == 1)
+            hipLaunchKernelGGL(conv_bf16_c32_kernel<1>, dim3(grid), dim3(256), 0, st, q);
+        else
+            hipLaunchKernelGGL(conv_bf16_c32_kernel<2>, dim3(grid), dim3(256), 0, st, q);
+        Y3_CHECK_LAUNCH("conv_bf16_c32");
         return Y3_OK;
     }
     if (p.Nout <= 32) {

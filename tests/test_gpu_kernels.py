@@ -160,6 +160,12 @@ BF16_CASES = [
     (1, 160, 160, 64, 1024, 3, 2, False, False), # stride 2 (asymmetric SAME padding)
     (1, 80, 80, 128, 1024, 1, 1, True, False),   # 2 K tiles, residual
     (1, 78, 80, 192, 1024, 1, 1, False, False),  # non-power-of-two Cin (1x1), 3 K tiles
+    # the patch kernel (conv_bf16_c32_kernel: 3x3, Cin 32 -> Cout 64; the two stride-2 cases near the top run on it too)
+    (2, 40, 45, 32, 64, 3, 1, True, False),      # stride 1, residual, ragged strip (45 = 32 + 13) and row group (40 = 5 x 8)
+    (1, 13, 70, 32, 64, 3, 1, False, False),     # rows not a multiple of the group, three strips
+    (6, 256, 256, 32, 64, 3, 1, True, False),    # 1 536 groups on 512 workgroups: three groups each (both LDS buffers re-used)
+    (2, 67, 131, 32, 64, 3, 2, False, False),    # stride 2, odd sizes (SAME padding before = 1), three strips
+    (5, 256, 256, 32, 64, 3, 2, False, False),   # stride 2, even sizes (padding after only), 640 groups on 512 workgroups
 ]
 
 
