@@ -1133,6 +1133,230 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_c32_kernel(const PatchArgs p
 }
 
 // ---------------------------------------------------------------------------
+// The same patch scheme for 3x3, Cin = 64 -> Cout = 128 (the 304^2 -> 152^2 stage): 8 waves = 4 channel blocks (cb = wave & 3)
+// x 2 K HALVES (kh2 = wave >> 2: input channels 32 kh2 .. + 31), so that a wave's weights are again 18 fragments = 72 VGPRs.
+// Every wave multiplies all RPG rows of the group over its half of K; the two waves of a channel block then exchange halves
+// of their accumulators through LDS (wave kh2 finishes rows kh2 * RPG / 2 ..: it parks the partial sums of the OTHER rows,
+// one barrier, and adds its partner's) and run the register epilogue of their rows.  Pixels are 128 B in LDS (8 slots,
+// slot ^= (idx >> 1) & 7: conflict-free fragment reads); one workgroup per CU (2 patch buffers + 64 KB exchange buffer).
+// ---------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(512) void conv_bf16_c64_kernel(const PatchArgs p) {
+    constexpr int RPG = S == 1 ? 4 : 2, RF = RPG / 2;           // output rows per group / rows a wave finishes
+    constexpr int IR = (RPG - 1) * S + 3, IC = 31 * S + 3;      // patch rows / columns
+    constexpr int PLANEB = 34 * 128;
+    constexpr int ROWB = S * PLANEB, BUFB = IR * ROWB;
+    constexpr int QUADS = IR * IC * 8, NL = (QUADS + 511) / 512;
+    constexpr int PL = IR;                                      // patch rows a wave reads: all of them
+    constexpr int REDB = 8 * RF * 16 * 64 * 4;                  // exchange buffer: [wave][row][register][lane] floats
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFB + REDB + 3 * 128 * 4];
+    unsigned char* red = smem + 2 * BUFB;
+    float* epi = reinterpret_cast<float*>(smem + 2 * BUFB + REDB);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int cb = wave & 3, kh2 = wave >> 2;
+    const int g_begin = (int)((long long)blockIdx.x * p.groups / gridDim.x), g_end = (int)((long long)(blockIdx.x + 1) * p.groups / gridDim.x);
+    if (g_begin >= g_end) return;
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.src), 0, p.src_bytes, 0x00020000);
+    const int aH = p.H, aW = p.W, src_ld = p.src_ld;
+
+    auto quad = [&](int t, int i, int& row, int& px, int& slot) {
+        const int q = t + 512 * i;
+        row = q / (IC * 8);
+        const int rem = q - row * (IC * 8);
+        px = rem >> 3;
+        slot = rem & 7;
+    };
+    auto decode = [&](int g, int& img, int& oy0, int& ox0) {
+        const int t = y3_div(g, p.dv_rg), rgi = g - t * p.rg;
+        img = y3_div(t, p.dv_xs);
+        oy0 = rgi * RPG;
+        ox0 = (t - img * p.xs) * 32;
+    };
+    f32x4 nxt[NL];
+    auto gload = [&](int g, bool live) {         // unconditional loads, see conv_bf16_c32_kernel
+        int img, oy0, ox0;
+        decode(g, img, oy0, ox0);
+        const int iy0 = oy0 * S - p.pbh, ix0 = ox0 * S - p.pbw;
+        const int base = ((img * aH + iy0) * aW + ix0) * src_ld * 2;
+        int t = tid;
+        asm volatile("" : "+v"(t));
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            int row, px, slot;
+            quad(t, i, row, px, slot);
+            const int iy = iy0 + row, ix = ix0 + px;
+            const bool ok = live & (row < IR) & ((unsigned)iy < (unsigned)aH) & ((unsigned)ix < (unsigned)aW);
+            nxt[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, ok ? (unsigned)(base + ((row * aW + px) * src_ld + slot * 8) * 2) : Y3_OOB, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            int row, px, slot;
+            quad(t, i, row, px, slot);
+            const int idx = S == 1 ? px : px >> 1, plane = S == 1 ? 0 : px & 1;
+            if (i + 1 < NL || row < IR)
+                *reinterpret_cast<f32x4*>(smem + buf * BUFB + row * ROWB + plane * PLANEB + idx * 128 + ((slot ^ ((idx >> 1) & 7)) << 4)) = nxt[i];
+        }
+    };
+    gload(g_begin, true);
+
+    // weights: A operand, lane = (channel cb * 32 + l31, k = lh * 8 .. + 7 of the 16-channel step kq of the wave's K half)
+    bf16x8 wf[3][3][2];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int kq = 0; kq < 2; ++kq)
+                wf[ky][kx][kq] = *reinterpret_cast<const bf16x8*>(p.wt + ((ky * 3 + kx) * 128 + cb * 32 + l31) * 64 + kh2 * 32 + kq * 16 + lh * 8);
+    if (tid < 128) {
+        epi[tid] = p.bias ? p.bias[tid] : 0.f;
+        epi[128 + tid] = p.scale ? p.scale[tid] : 1.f;
+        epi[256 + tid] = p.scale ? p.shift[tid] : 0.f;
+    }
+    int b_addr[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+            const int idx = S == 1 ? l31 + kx : l31 + (kx >> 1), plane = S == 1 ? 0 : kx & 1, slot = kh2 * 4 + kq * 2 + lh;
+            b_addr[kx][kq] = plane * PLANEB + idx * 128 + ((slot ^ ((idx >> 1) & 7)) << 4);
+        }
+    const bool do_lrelu = p.flags & Y3_EPI_LRELU;
+    const bool has_scale = p.scale != nullptr;
+    const float alpha = p.alpha;
+    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.resid ? p.resid : p.src), 0, p.resid_bytes, 0x00020000);
+    const int aOH = p.OH, aOW = p.OW, dst_ld = p.dst_ld, resid_ld = p.resid_ld;
+
+    lstore(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the weights have landed
+    __syncthreads();
+    int buf = 0;
+#pragma unroll 1
+    for (int g = g_begin; g < g_end; ++g, buf ^= 1) {
+        const bool more = g + 1 < g_end;
+        gload(g + 1, more);
+        __builtin_amdgcn_sched_barrier(0);
+        int img, oy0, ox0;
+        decode(g, img, oy0, ox0);
+        f32x16 acc[RPG];
+#pragma unroll
+        for (int r = 0; r < RPG; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+        const unsigned char* bb = smem + buf * BUFB;
+        bf16x8 bf[2][3][2];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int kq = 0; kq < 2; ++kq) bf[0][kx][kq] = *reinterpret_cast<const bf16x8*>(bb + b_addr[kx][kq]);
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) {
+            if (pl + 1 < PL) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int kq = 0; kq < 2; ++kq) bf[(pl + 1) & 1][kx][kq] = *reinterpret_cast<const bf16x8*>(bb + b_addr[kx][kq] + (pl + 1) * ROWB);
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+                    for (int r = 0; r < RPG; ++r) {
+                        const int ky = pl - r * S;
+                        if (ky >= 0 && ky < 3) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ky][kx][kq], bf[pl & 1][kx][kq], acc[r], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the residual of this wave's rows is requested before the exchange (its latency hides behind the barrier)
+        const int ox = ox0 + l31;
+        unsigned o_dst[RF];
+        f32x4 rv[RF][2];
+#pragma unroll
+        for (int r = 0; r < RF; ++r) {
+            const int oy = oy0 + kh2 * RF + r;
+            const bool valid = oy < aOH && ox < aOW;
+            const int m = (img * aOH + oy) * aOW + ox;
+            o_dst[r] = valid ? (unsigned)(m * dst_ld + cb * 32 + 8 * lh) * 2u : Y3_OOB;
+            const unsigned o_res = valid ? (unsigned)(m * resid_ld + cb * 32 + 8 * lh) * 2u : Y3_OOB;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) rv[r][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, o_res, e * 32, 0);
+        }
+        // exchange: park the partial sums of the rows the PARTNER finishes (rows (1 - kh2) * RF ..), then add the partner's
+        {
+            unsigned char* mine = red + (wave * RF) * 4096 + lane * 16;
+#pragma unroll
+            for (int r = 0; r < RF; ++r)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {                   // (a wave-uniform select between two register sets, not an indexed array)
+                    const f32x4 v0 = f32x4{acc[RF + r][4 * e4], acc[RF + r][4 * e4 + 1], acc[RF + r][4 * e4 + 2], acc[RF + r][4 * e4 + 3]};
+                    const f32x4 v1 = f32x4{acc[r][4 * e4], acc[r][4 * e4 + 1], acc[r][4 * e4 + 2], acc[r][4 * e4 + 3]};
+                    *reinterpret_cast<f32x4*>(mine + r * 4096 + e4 * 1024) = kh2 == 0 ? v0 : v1;
+                }
+        }
+        y3_lds_barrier();
+        f32x16 fin[RF];
+        {
+            const unsigned char* theirs = red + ((wave ^ 4) * RF) * 4096 + lane * 16;
+#pragma unroll
+            for (int r = 0; r < RF; ++r)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(theirs + r * 4096 + e4 * 1024);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fin[r][4 * e4 + j] = (kh2 == 0 ? acc[r][4 * e4 + j] : acc[RF + r][4 * e4 + j]) + o[j];
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // epilogue: fin[r][4 g + j] = channel cb * 32 + 8 g + 4 lh + j of pixel (oy0 + kh2 * RF + r, ox0 + l31)
+#pragma unroll
+        for (int r = 0; r < RF; ++r) {
+            float v[16];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int c = cb * 32 + 8 * gq + 4 * lh;
+                const f32x4 eb = *reinterpret_cast<const f32x4*>(epi + c), es = *reinterpret_cast<const f32x4*>(epi + 128 + c),
+                            ef = *reinterpret_cast<const f32x4*>(epi + 256 + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = fin[r][4 * gq + j] + eb[j];
+                    if (do_lrelu) x = x > 0.f ? x : alpha * x;
+                    if (has_scale) x = x * es[j] + ef[j];
+                    v[4 * gq + j] = x;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Y3_SWAP32(v[8 * e + j], v[8 * e + 4 + j]);
+                float* w = v + 8 * e;
+                const f32x4 rr = rv[r][e];
+                unsigned pk[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned rw = __float_as_uint(rr[q]);
+                    const float lo = w[2 * q] + __uint_as_float(rw << 16), hi = w[2 * q + 1] + __uint_as_float(rw & 0xffff0000u);
+                    pk[q] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(f32x4{__uint_as_float(pk[0]), __uint_as_float(pk[1]), __uint_as_float(pk[2]), __uint_as_float(pk[3])},
+                                                       rs_dst, o_dst[r], e * 32, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) lstore(buf ^ 1);
+        y3_lds_barrier();                        // orders the patch buffers AND the exchange buffer of the next group
+    }
+}
+
+// ---------------------------------------------------------------------------
 // small bf16 helpers
 // ---------------------------------------------------------------------------
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, size_t count) {
@@ -1401,6 +1625,42 @@ static int conv2d_fwd_bf16_impl(const y3_tensor* src, const void* wt_t_bf16, con
         else
             hipLaunchKernelGGL(conv_bf16_c32_kernel<2>, dim3(grid), dim3(256), 0, st, q);
         Y3_CHECK_LAUNCH("conv_bf16_c32");
+        return Y3_OK;
+    }
+    if (patch_on && ksize == 3 && stride == 1 && p.C == 64 && p.Nout == 128 && !dst_is_f32 && p.vec_ok && ((uintptr_t)wt_t_bf16 & 15) == 0 &&
+        src->h < 0x4000 && src->w < 0x4000) {
+        PatchArgs q = {};
+        q.src = (const u16*)src->ptr;
+        q.wt = (const u16*)wt_t_bf16;
+        q.dst = (u16*)dst->ptr;
+        q.bias = bias;
+        q.scale = scale;
+        q.shift = shift;
+        q.resid = p.resid;
+        q.src_bytes = (unsigned)((long long)src->n * src->h * src->w * src->ld * 2);
+        q.dst_bytes = p.dst_bytes;
+        q.resid_bytes = p.resid ? p.resid_bytes : 0u;
+        q.H = src->h;
+        q.W = src->w;
+        q.OH = OH;
+        q.OW = OW;
+        q.src_ld = src->ld;
+        q.dst_ld = dst->ld;
+        q.resid_ld = p.resid_ld;
+        q.pbh = pbh;
+        q.pbw = pbw;
+        q.xs = y3_cdiv(OW, 32);
+        q.rg = y3_cdiv(OH, 4);
+        const long long groups = (long long)src->n * q.xs * q.rg;
+        Y3_CHECK_ARG(groups < 0x7fffffffLL, "conv2d_fwd_bf16: too many row groups");
+        q.groups = (int)groups;
+        q.dv_rg = y3_make_div(q.rg);
+        q.dv_xs = y3_make_div(q.xs);
+        q.flags = flags;
+        q.alpha = alpha;
+        const unsigned grid = (unsigned)(groups < 256 ? groups : 256);       // one workgroup of 8 waves per CU
+        hipLaunchKernelGGL(conv_bf16_c64_kernel<1>, dim3(grid), dim3(512), 0, st, q);
+        Y3_CHECK_LAUNCH("conv_bf16_c64");
         return Y3_OK;
     }
     if (p.Nout <= 32) {
