@@ -1627,7 +1627,7 @@ static int conv2d_fwd_bf16_impl(const y3_tensor* src, const void* wt_t_bf16, con
         Y3_CHECK_LAUNCH("conv_bf16_c32");
         return Y3_OK;
     }
-    if (patch_on && ksize == 3 && stride == 1 && p.C == 64 && p.Nout == 128 && !dst_is_f32 && p.vec_ok && ((uintptr_t)wt_t_bf16 & 15) == 0 &&
+    if (patch_on && ksize == 3 && p.C == 64 && p.Nout == 128 && !dst_is_f32 && p.vec_ok && ((uintptr_t)wt_t_bf16 & 15) == 0 &&
         src->h < 0x4000 && src->w < 0x4000) {
         PatchArgs q = {};
         q.src = (const u16*)src->ptr;
@@ -1650,7 +1650,7 @@ static int conv2d_fwd_bf16_impl(const y3_tensor* src, const void* wt_t_bf16, con
         q.pbh = pbh;
         q.pbw = pbw;
         q.xs = y3_cdiv(OW, 32);
-        q.rg = y3_cdiv(OH, 4);
+        q.rg = y3_cdiv(OH, stride == 1 ? 4 : 2);
         const long long groups = (long long)src->n * q.xs * q.rg;
         Y3_CHECK_ARG(groups < 0x7fffffffLL, "conv2d_fwd_bf16: too many row groups");
         q.groups = (int)groups;
@@ -1659,7 +1659,10 @@ static int conv2d_fwd_bf16_impl(const y3_tensor* src, const void* wt_t_bf16, con
         q.flags = flags;
         q.alpha = alpha;
         const unsigned grid = (unsigned)(groups < 256 ? groups : 256);       // one workgroup of 8 waves per CU
-        hipLaunchKernelGGL(conv_bf16_c64_kernel<1>, dim3(grid), dim3(512), 0, st, q);
+        if (stride == 1)
+            hipLaunchKernelGGL(conv_bf16_c64_kernel<1>, dim3(grid), dim3(512), 0, st, q);
+        else
+            hipLaunchKernelGGL(conv_bf16_c64_kernel<2>, dim3(grid), dim3(512), 0, st, q);
         Y3_CHECK_LAUNCH("conv_bf16_c64");
         return Y3_OK;
     }

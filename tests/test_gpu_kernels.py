@@ -170,6 +170,8 @@ BF16_CASES = [
     (2, 40, 45, 64, 128, 3, 1, True, False),     # ragged strip, residual
     (1, 9, 70, 64, 128, 3, 1, False, False),     # rows not a multiple of the group (9 = 2 x 4 + 1), three strips
     (3, 152, 152, 64, 128, 3, 1, True, False),   # 570 groups on 256 workgroups: both patch buffers and the exchange buffer re-used
+    (2, 67, 131, 64, 128, 3, 2, False, False),   # stride 2 (two planes of 128-byte pixels), odd sizes
+    (2, 160, 160, 64, 128, 3, 2, False, False),  # stride 2, even sizes, 480 groups on 256 workgroups
 ]
 
 
