@@ -933,7 +933,7 @@ struct PatchArgs {
     float alpha;
 };
 
-template <int S>
+template <int S, bool RES>
 __global__ __launch_bounds__(256, 2) void conv_bf16_c32_kernel(const PatchArgs p) {
     constexpr int RPG = S == 1 ? 8 : 4, RW = RPG / 2;          // output rows per group / per wave
     constexpr int IR = (RPG - 1) * S + 3, IC = 31 * S + 3;      // patch rows / columns
@@ -1087,7 +1087,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_c32_kernel(const PatchArgs p
             o_dst[r] = valid ? (unsigned)(m * dst_ld + cb * 32 + 8 * lh) * 2u : Y3_OOB;
             const unsigned o_res = valid ? (unsigned)(m * resid_ld + cb * 32 + 8 * lh) * 2u : Y3_OOB;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) rv[r][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, o_res, e * 32, 0);
+            for (int e = 0; e < 2; ++e) {
+                // without a residual (RES = false) there is NO load here: loads return in order, so even an out-of-range request
+                // would make the first store wait for the patch of the next group as well
+                if constexpr (RES)
+                    rv[r][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, o_res, e * 32, 0);
+                else
+                    rv[r][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1117,7 +1124,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_c32_kernel(const PatchArgs p
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const unsigned rw = __float_as_uint(rr[q]);
-                    const float lo = w[2 * q] + __uint_as_float(rw << 16), hi = w[2 * q + 1] + __uint_as_float(rw & 0xffff0000u);
+                    const float lo = RES ? w[2 * q] + __uint_as_float(rw << 16) : w[2 * q], hi = RES ? w[2 * q + 1] + __uint_as_float(rw & 0xffff0000u) : w[2 * q + 1];
                     pk[q] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(f32x4{__uint_as_float(pk[0]), __uint_as_float(pk[1]), __uint_as_float(pk[2]), __uint_as_float(pk[3])},
@@ -1620,10 +1627,14 @@ static int conv2d_fwd_bf16_impl(const y3_tensor* src, const void* wt_t_bf16, con
         q.flags = flags;
         q.alpha = alpha;
         const unsigned grid = (unsigned)(groups < 512 ? groups : 512);       // two workgroups per CU, each a contiguous run of groups
-        if (stride == 1)
-            hipLaunchKernelGGL(conv_bf16_c32_kernel<1>, dim3(grid), dim3(256), 0, st, q);
+        if (stride == 1 && q.resid)
+            hipLaunchKernelGGL((conv_bf16_c32_kernel<1, true>), dim3(grid), dim3(256), 0, st, q);
+        else if (stride == 1)
+            hipLaunchKernelGGL((conv_bf16_c32_kernel<1, false>), dim3(grid), dim3(256), 0, st, q);
+        else if (q.resid)
+            hipLaunchKernelGGL((conv_bf16_c32_kernel<2, true>), dim3(grid), dim3(256), 0, st, q);
         else
-            hipLaunchKernelGGL(conv_bf16_c32_kernel<2>, dim3(grid), dim3(256), 0, st, q);
+            hipLaunchKernelGGL((conv_bf16_c32_kernel<2, false>), dim3(grid), dim3(256), 0, st, q);
         Y3_CHECK_LAUNCH("conv_bf16_c32");
         return Y3_OK;
     }

@@ -166,6 +166,7 @@ BF16_CASES = [
     (6, 256, 256, 32, 64, 3, 1, True, False),    # 1 536 groups on 512 workgroups: three groups each (both LDS buffers re-used)
     (2, 67, 131, 32, 64, 3, 2, False, False),    # stride 2, odd sizes (SAME padding before = 1), three strips
     (5, 256, 256, 32, 64, 3, 2, False, False),   # stride 2, even sizes (padding after only), 640 groups on 512 workgroups
+    (2, 30, 40, 32, 64, 3, 2, True, False),      # stride 2 with a residual (the fourth instantiation)
     # conv_bf16_c64_kernel (3x3 stride 1, Cin 64 -> Cout 128: two K halves per channel block, exchanged through LDS)
     (2, 40, 45, 64, 128, 3, 1, True, False),     # ragged strip, residual
     (1, 9, 70, 64, 128, 3, 1, False, False),     # rows not a multiple of the group (9 = 2 x 4 + 1), three strips
