@@ -281,6 +281,51 @@ def test_conv_bf16_pingpong_kernel_is_race_free_at_benchmark_shape(hip):
     assert bool(torch.isfinite(got).all()) and bool(((got - ref).abs() <= bound).all()), 'max excess %.3e' % float(((got - ref).abs() - bound).max())
 
 
+@pytest.mark.parametrize('shape', [(8, 304, 304, 32, 64, 1), (4, 608, 608, 32, 64, 2), (8, 152, 152, 64, 128, 1), (6, 304, 304, 64, 128, 2)])
+def test_conv_bf16_patch_kernels_are_race_free_at_tiled_shapes(hip, shape):
+    """conv_bf16_c32_kernel / conv_bf16_c64_kernel at the shapes of the tiled path's 608^2 -> 152^2 stages (a few tiles: every
+    workgroup walks 5-12 row groups, so both LDS patch buffers -- and, for c64, the accumulator exchange buffer -- are re-used
+    many times between barriers): 20 launches must give the same bits, with a residual at stride 1 as in the network, and those
+    bits must agree with the fp32 MFMA kernel on the same bf16-representable operands (exact products; fp32 accumulation order
+    + one bf16 rounding: half an ulp + 2e-5 of scale)."""
+    from util import stream
+    n, h, w, cin, cout, s = shape
+    k = 3
+    oh, ow = -(-h // s), -(-w // s)
+    g = torch.Generator().manual_seed(5 + cin + s)
+    xd = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16).cuda()
+    wk = (torch.randn(k, k, cin, cout, generator=g) * 0.08).to(torch.bfloat16)
+    bd = torch.randn(cout, generator=g).cuda()
+    rd = torch.randn(n, oh, ow, cout, generator=g).to(torch.bfloat16).cuda() if s == 1 else None
+    wf = wk.float().contiguous().cuda()
+    wt = torch.empty(k * k * cout * cin, device='cuda')
+    hip.check(hip.lib.y3_transpose_weights(wf.data_ptr(), wt.data_ptr(), k * k, cin, cout, stream()))
+    wtb = torch.empty(k * k * cout * cin, dtype=torch.bfloat16, device='cuda')
+    hip.check(hip.lib.y3_f32_to_bf16(wt.data_ptr(), wtb.data_ptr(), wt.numel(), stream()))
+    src = hip.Tensor(xd.data_ptr(), n, h, w, cin, cin)
+    res = hip.Tensor(rd.data_ptr(), n, oh, ow, cout, cout) if rd is not None else None
+    y = torch.empty(n, oh, ow, cout, dtype=torch.bfloat16, device='cuda')
+    for rep in range(20):
+        y.fill_(float('nan'))
+        hip.check(hip.lib.y3_conv2d_fwd_bf16(src, wtb.data_ptr(), bd.data_ptr(), k, s, hip.Tensor(y.data_ptr(), n, oh, ow, cout, cout), 0,
+                                             hip.EPI_LRELU, 0.2, None, None, res, stream()))
+        if rep == 0:
+            first = y.clone()
+        else:
+            assert torch.equal(y.view(torch.int16), first.view(torch.int16)), 'launch %d differs from launch 0' % rep
+    x32 = xd.float().contiguous()
+    y32 = torch.empty(n, oh, ow, cout, device='cuda')
+    wsb = int(hip.lib.y3_conv2d_fwd_workspace(n * oh * ow, cin, k, cout))
+    ws = torch.zeros(wsb // 4 + 4, device='cuda')
+    hip.check(hip.lib.y3_conv2d_fwd(hip.Tensor(x32.data_ptr(), n, h, w, cin, cin), wf.data_ptr(), bd.data_ptr(), k, s,
+                                    hip.Tensor(y32.data_ptr(), n, oh, ow, cout, cout), hip.EPI_LRELU, 0.2, None, None, None, None, ws.data_ptr(), wsb, stream()))
+    ref = y32.double() + (rd.double() if rd is not None else 0.0)
+    got = first.double()
+    scale = float(ref.abs().max())
+    bound = ref.abs() * 2.0 ** -8 + 2e-5 * scale
+    assert bool(torch.isfinite(got).all()) and bool(((got - ref).abs() <= bound).all()), 'max excess %.3e' % float(((got - ref).abs() - bound).max())
+
+
 def test_conv_first_bf16(hip):
     """y3_conv2d_first_bf16 (direct fp32 convolution of the RGB layer, bf16 store) vs fp64: half a bf16 ulp + 1e-5 of scale."""
     from util import nhwc_buf, stream
