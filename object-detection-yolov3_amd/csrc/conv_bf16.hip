@@ -948,7 +948,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_c32_kernel(const PatchArgs p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int cb = wave & 1, rs = wave >> 1;
-    const int g_begin = (int)((long long)blockIdx.x * p.groups / gridDim.x), g_end = (int)((long long)(blockIdx.x + 1) * p.groups / gridDim.x);
+    const int bid = y3_xcd_remap(blockIdx.x, gridDim.x);       // neighbouring runs (halo columns / rows in common) behind the same L2
+    const int g_begin = (int)((long long)bid * p.groups / gridDim.x), g_end = (int)((long long)(bid + 1) * p.groups / gridDim.x);
     if (g_begin >= g_end) return;
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.src), 0, p.src_bytes, 0x00020000);
     const int aH = p.H, aW = p.W, src_ld = p.src_ld;
@@ -1164,7 +1165,8 @@ __global__ __launch_bounds__(512) void conv_bf16_c64_kernel(const PatchArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int cb = wave & 3, kh2 = wave >> 2;
-    const int g_begin = (int)((long long)blockIdx.x * p.groups / gridDim.x), g_end = (int)((long long)(blockIdx.x + 1) * p.groups / gridDim.x);
+    const int bid = y3_xcd_remap(blockIdx.x, gridDim.x);       // neighbouring runs (halo columns / rows in common) behind the same L2
+    const int g_begin = (int)((long long)bid * p.groups / gridDim.x), g_end = (int)((long long)(bid + 1) * p.groups / gridDim.x);
     if (g_begin >= g_end) return;
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.src), 0, p.src_bytes, 0x00020000);
     const int aH = p.H, aW = p.W, src_ld = p.src_ld;
