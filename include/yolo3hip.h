@@ -254,12 +254,16 @@ int y3_upsample_sum2x_bwd(const y3_tensor* dout, const y3_tensor* din, y3_stream
  * v_mfma_f32_32x32x16_bf16, fp32 epilogue (bias, lrelu, folded BN scale/shift, residual), one rounding on store.
  * wt_t_bf16 is the y3_transpose_weights layout [kh][kw][Cout][Cin] converted with y3_f32_to_bf16.
  * Requires Cin % 32 == 0 (the first RGB layer stays on y3_conv2d_fwd).  dst_is_f32 != 0 writes fp32
- * (used for the three head convs so that decode / NMS stay fp32). */
+ * (used for the three head convs so that decode / NMS stay fp32).
+ * Which kernel runs is the library's choice and does not change the contract: the 3x3 layers 32 -> 64 and 64 -> 128 with bf16
+ * output and 16-byte aligned rows (the 608^2 -> 152^2 stages of the tiled path) take HBM-bound patch kernels (input patch once
+ * through LDS, weights in registers), Cin % 64 == 0 with Cout >= 256 and >= 96 tiles of 256 x 256 the ping-pong kernel, the rest
+ * the LDS-DMA ring kernel.  All of them accumulate in fp32 and round once. */
 int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, const float* bias, int ksize, int stride,
                        const y3_tensor* dst, int dst_is_f32, unsigned flags, float alpha,
                        const float* scale, const float* shift, const y3_tensor* resid, y3_stream_t stream);
 /* The same with a caller-owned workspace (y3_conv2d_fwd_bf16_workspace(m = N*OH*OW, cin, ksize, cout) bytes; zero it once, the
- * first 64 KiB are per-tile tickets that every launch leaves at zero; one stream per workspace): the small-M layers
+ * first 256 KiB are per-tile tickets (the same header as the fp32 entries, so one zeroed workspace can serve both) that every launch leaves at zero; one stream per workspace): the small-M layers
  * (<= 1 024 tiles of 64 x 64 and >= 32 K steps: the 13x13 / 26x26 / 19x19 grids at batch 8) are then split along K into up to 8
  * slices whose fp32 partial sums the last-arriving slice adds in slice order inside the kernel (bit-reproducible).  Without a
  * workspace (or with y3_conv2d_fwd_bf16) every tile walks its whole K. */
