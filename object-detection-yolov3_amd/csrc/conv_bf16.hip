@@ -954,15 +954,26 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_c32_kernel(const PatchArgs p
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.src), 0, p.src_bytes, 0x00020000);
     const int aH = p.H, aW = p.W, src_ld = p.src_ld;
 
-    // the quads this thread stages: q = tid + 256 i -> (patch row, column, 16-byte slot); recomputed where needed (a few integer
-    // operations with constant divisors) rather than kept in 3 NL registers beside 72 of weights and 64 of accumulators
-    auto quad = [&](int t, int i, int& row, int& px, int& slot) {
-        const int q = t + 256 * i;
-        row = q / (IC * 4);
-        const int rem = q - row * (IC * 4);
-        px = rem >> 2;
-        slot = rem & 3;
+    // Staging map (a thread's share of a patch), chosen so that NOTHING of the quad decode is left in the group loop -- the first
+    // version decoded q = tid + 256 i with constant divisions per load and group: with the predicates and the LDS address that was
+    // ~40 vector instructions per load, and the stride-2 c32 launch was bound by the vector ALU (1 340 VALU instructions per wave and
+    // group beside 36 MFMAs; `profiles/r04_pmc_bf16_patch_before_valu.txt`).  MAIN loads: stride 1: two patch rows x 32 pixels
+    // per load (r2 = row parity of the thread), stride 2: one row x 64 pixels; load i covers rows RPL i (+ r2), so its global
+    // offset is the thread's own offset + i x a scalar and its LDS address the thread's own + an immediate.  ONE extra load takes the
+    // remaining 2 S^-1.. pixels per row (stride 1: columns 32, 33; stride 2: column 64) for all rows.
+    constexpr int SL = 4;                                    // 16-byte slots per pixel
+    constexpr int RPL = S == 1 ? 2 : 1, PXL = S == 1 ? 32 : 64, NM = IR / RPL, XP = IC - PXL;   // rows / pixels per main load, main loads, extra pixels per row
+    static_assert(NM * RPL == IR && RPL * PXL * SL == 256 && NM + 1 == NL && IR * XP * SL <= 256, "staging map");
+    const int m_r2 = S == 1 ? tid / (PXL * SL) : 0, m_px = (tid / SL) % PXL, m_slot = tid % SL;
+    const int e_row = tid / (XP * SL), e_px = PXL + (tid / SL) % XP, e_slot = tid % SL;
+    const bool e_live = tid < IR * XP * SL;
+    auto lds_of = [&](int row, int px, int slot) {
+        const int idx = S == 1 ? px : px >> 1, plane = S == 1 ? 0 : px & 1;
+        return row * ROWB + plane * PLANEB + idx * 64 + ((slot ^ ((idx >> 2) & 3)) << 4);
     };
+    const int m_lds = lds_of(m_r2, m_px, m_slot), e_lds = lds_of(e_live ? e_row : 0, e_px, e_slot);
+    const int m_goff = ((m_r2 * aW + m_px) * src_ld + m_slot * 8) * 2, e_goff = ((e_row * aW + e_px) * src_ld + e_slot * 8) * 2;
+    const int row_pitch = RPL * aW * src_ld * 2;               // bytes between the rows of consecutive main loads
     auto decode = [&](int g, int& img, int& oy0, int& ox0) {
         const int t = y3_div(g, p.dv_rg), rgi = g - t * p.rg;
         img = y3_div(t, p.dv_xs);
@@ -976,29 +987,22 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_c32_kernel(const PatchArgs p
         int img, oy0, ox0;
         decode(g, img, oy0, ox0);
         const int iy0 = oy0 * S - p.pbh, ix0 = ox0 * S - p.pbw;
-        const int base = ((img * aH + iy0) * aW + ix0) * src_ld * 2;   // may be negative; with the quad's own offset it is not, for a pixel inside the image
-        int t = tid;
-        asm volatile("" : "+v"(t));              // opaque: otherwise the quad decode is hoisted out of the group loop into 3 NL registers
+        const int base = ((img * aH + iy0) * aW + ix0) * src_ld * 2;   // may be negative; with a quad's own offset it is not, for a pixel inside the image
+        const bool okx = live & ((unsigned)(ix0 + m_px) < (unsigned)aW);
+        const int vbase = base + m_goff;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            int row, px, slot;
-            quad(t, i, row, px, slot);
-            const int iy = iy0 + row, ix = ix0 + px;
-            const bool ok = live & (row < IR) & ((unsigned)iy < (unsigned)aH) & ((unsigned)ix < (unsigned)aW);   // & not &&: no branches
-            nxt[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, ok ? (unsigned)(base + ((row * aW + px) * src_ld + slot * 8) * 2) : Y3_OOB, 0, 0);
+        for (int i = 0; i < NM; ++i) {
+            const bool ok = okx & ((unsigned)(iy0 + RPL * i + m_r2) < (unsigned)aH);
+            nxt[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, ok ? (unsigned)(vbase + i * row_pitch) : Y3_OOB, 0, 0);
         }
+        const bool eok = live & e_live & ((unsigned)(iy0 + e_row) < (unsigned)aH) & ((unsigned)(ix0 + e_px) < (unsigned)aW);
+        nxt[NM] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, eok ? (unsigned)(base + e_goff) : Y3_OOB, 0, 0);
     };
     auto lstore = [&](int buf) {
-        int t = tid;
-        asm volatile("" : "+v"(t));
+        unsigned char* mb = smem + buf * BUFB + m_lds;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            int row, px, slot;
-            quad(t, i, row, px, slot);
-            const int idx = S == 1 ? px : px >> 1, plane = S == 1 ? 0 : px & 1;
-            if (i + 1 < NL || row < IR)
-                *reinterpret_cast<f32x4*>(smem + buf * BUFB + row * ROWB + plane * PLANEB + idx * 64 + ((slot ^ ((idx >> 2) & 3)) << 4)) = nxt[i];
-        }
+        for (int i = 0; i < NM; ++i) *reinterpret_cast<f32x4*>(mb + i * RPL * ROWB) = nxt[i];
+        if (e_live) *reinterpret_cast<f32x4*>(smem + buf * BUFB + e_lds) = nxt[NM];
     };
     gload(g_begin, true);
 
@@ -1025,9 +1029,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_c32_kernel(const PatchArgs p
             const int idx = S == 1 ? l31 + kx : l31 + (kx >> 1), plane = S == 1 ? 0 : kx & 1, slot = kh * 2 + lh;
             b_addr[kx][kh] = rs * 4 * ROWB + plane * PLANEB + idx * 64 + ((slot ^ ((idx >> 2) & 3)) << 4);
         }
-    const bool do_lrelu = p.flags & Y3_EPI_LRELU;
-    const bool has_scale = p.scale != nullptr;
-    const float alpha = p.alpha;
+    const float alpha = (p.flags & Y3_EPI_LRELU) ? p.alpha : 1.f;   // flags folded into constants: no selects per value in the epilogue
     const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.resid ? p.resid : p.src), 0, p.resid_bytes, 0x00020000);
     const int aOH = p.OH, aOW = p.OW, dst_ld = p.dst_ld, resid_ld = p.resid_ld;
@@ -1109,8 +1111,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_c32_kernel(const PatchArgs p
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float x = acc[r][4 * gq + j] + eb[j];
-                    if (do_lrelu) x = x > 0.f ? x : alpha * x;
-                    if (has_scale) x = x * es[j] + ef[j];
+                    x = __builtin_fmaxf(x, alpha * x);       // leaky-relu for 0 <= alpha <= 1 (the host checks); alpha = 1 without one
+                    x = x * es[j] + ef[j];                   // scale 1, shift 0 without a folded BatchNorm
                     v[4 * gq + j] = x;
                 }
             }
@@ -1171,13 +1173,26 @@ __global__ __launch_bounds__(512) void conv_bf16_c64_kernel(const PatchArgs p) {
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.src), 0, p.src_bytes, 0x00020000);
     const int aH = p.H, aW = p.W, src_ld = p.src_ld;
 
-    auto quad = [&](int t, int i, int& row, int& px, int& slot) {
-        const int q = t + 512 * i;
-        row = q / (IC * 8);
-        const int rem = q - row * (IC * 8);
-        px = rem >> 3;
-        slot = rem & 7;
+    // Staging map (a thread's share of a patch), chosen so that NOTHING of the quad decode is left in the group loop -- the first
+    // version decoded q = tid + 512 i with constant divisions per load and group: with the predicates and the LDS address that was
+    // ~40 vector instructions per load, and the stride-2 c32 launch was bound by the vector ALU (1 340 VALU instructions per wave and
+    // group beside 36 MFMAs; `profiles/r04_pmc_bf16_patch_before_valu.txt`).  MAIN loads: stride 1: two patch rows x 32 pixels
+    // per load (r2 = row parity of the thread), stride 2: one row x 64 pixels; load i covers rows RPL i (+ r2), so its global
+    // offset is the thread's own offset + i x a scalar and its LDS address the thread's own + an immediate.  ONE extra load takes the
+    // remaining 2 S^-1.. pixels per row (stride 1: columns 32, 33; stride 2: column 64) for all rows.
+    constexpr int SL = 8;                                    // 16-byte slots per pixel
+    constexpr int RPL = S == 1 ? 2 : 1, PXL = S == 1 ? 32 : 64, NM = IR / RPL, XP = IC - PXL;   // rows / pixels per main load, main loads, extra pixels per row
+    static_assert(NM * RPL == IR && RPL * PXL * SL == 512 && NM + 1 == NL && IR * XP * SL <= 512, "staging map");
+    const int m_r2 = S == 1 ? tid / (PXL * SL) : 0, m_px = (tid / SL) % PXL, m_slot = tid % SL;
+    const int e_row = tid / (XP * SL), e_px = PXL + (tid / SL) % XP, e_slot = tid % SL;
+    const bool e_live = tid < IR * XP * SL;
+    auto lds_of = [&](int row, int px, int slot) {
+        const int idx = S == 1 ? px : px >> 1, plane = S == 1 ? 0 : px & 1;
+        return row * ROWB + plane * PLANEB + idx * 128 + ((slot ^ ((idx >> 1) & 7)) << 4);
     };
+    const int m_lds = lds_of(m_r2, m_px, m_slot), e_lds = lds_of(e_live ? e_row : 0, e_px, e_slot);
+    const int m_goff = ((m_r2 * aW + m_px) * src_ld + m_slot * 8) * 2, e_goff = ((e_row * aW + e_px) * src_ld + e_slot * 8) * 2;
+    const int row_pitch = RPL * aW * src_ld * 2;               // bytes between the rows of consecutive main loads
     auto decode = [&](int g, int& img, int& oy0, int& ox0) {
         const int t = y3_div(g, p.dv_rg), rgi = g - t * p.rg;
         img = y3_div(t, p.dv_xs);
@@ -1185,33 +1200,28 @@ __global__ __launch_bounds__(512) void conv_bf16_c64_kernel(const PatchArgs p) {
         ox0 = (t - img * p.xs) * 32;
     };
     f32x4 nxt[NL];
-    auto gload = [&](int g, bool live) {         // unconditional loads, see conv_bf16_c32_kernel
+    // every memory operation of the loop is UNCONDITIONAL (out-of-range offsets instead of branches): the compiler's vmcnt
+    // bookkeeping is then exact and a wait for one load does not degrade to vmcnt(0), which would end the prefetch early
+    auto gload = [&](int g, bool live) {
         int img, oy0, ox0;
         decode(g, img, oy0, ox0);
         const int iy0 = oy0 * S - p.pbh, ix0 = ox0 * S - p.pbw;
-        const int base = ((img * aH + iy0) * aW + ix0) * src_ld * 2;
-        int t = tid;
-        asm volatile("" : "+v"(t));
+        const int base = ((img * aH + iy0) * aW + ix0) * src_ld * 2;   // may be negative; with a quad's own offset it is not, for a pixel inside the image
+        const bool okx = live & ((unsigned)(ix0 + m_px) < (unsigned)aW);
+        const int vbase = base + m_goff;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            int row, px, slot;
-            quad(t, i, row, px, slot);
-            const int iy = iy0 + row, ix = ix0 + px;
-            const bool ok = live & (row < IR) & ((unsigned)iy < (unsigned)aH) & ((unsigned)ix < (unsigned)aW);
-            nxt[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, ok ? (unsigned)(base + ((row * aW + px) * src_ld + slot * 8) * 2) : Y3_OOB, 0, 0);
+        for (int i = 0; i < NM; ++i) {
+            const bool ok = okx & ((unsigned)(iy0 + RPL * i + m_r2) < (unsigned)aH);
+            nxt[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, ok ? (unsigned)(vbase + i * row_pitch) : Y3_OOB, 0, 0);
         }
+        const bool eok = live & e_live & ((unsigned)(iy0 + e_row) < (unsigned)aH) & ((unsigned)(ix0 + e_px) < (unsigned)aW);
+        nxt[NM] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, eok ? (unsigned)(base + e_goff) : Y3_OOB, 0, 0);
     };
     auto lstore = [&](int buf) {
-        int t = tid;
-        asm volatile("" : "+v"(t));
+        unsigned char* mb = smem + buf * BUFB + m_lds;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            int row, px, slot;
-            quad(t, i, row, px, slot);
-            const int idx = S == 1 ? px : px >> 1, plane = S == 1 ? 0 : px & 1;
-            if (i + 1 < NL || row < IR)
-                *reinterpret_cast<f32x4*>(smem + buf * BUFB + row * ROWB + plane * PLANEB + idx * 128 + ((slot ^ ((idx >> 1) & 7)) << 4)) = nxt[i];
-        }
+        for (int i = 0; i < NM; ++i) *reinterpret_cast<f32x4*>(mb + i * RPL * ROWB) = nxt[i];
+        if (e_live) *reinterpret_cast<f32x4*>(smem + buf * BUFB + e_lds) = nxt[NM];
     };
     gload(g_begin, true);
 
@@ -1237,9 +1247,7 @@ __global__ __launch_bounds__(512) void conv_bf16_c64_kernel(const PatchArgs p) {
             const int idx = S == 1 ? l31 + kx : l31 + (kx >> 1), plane = S == 1 ? 0 : kx & 1, slot = kh2 * 4 + kq * 2 + lh;
             b_addr[kx][kq] = plane * PLANEB + idx * 128 + ((slot ^ ((idx >> 1) & 7)) << 4);
         }
-    const bool do_lrelu = p.flags & Y3_EPI_LRELU;
-    const bool has_scale = p.scale != nullptr;
-    const float alpha = p.alpha;
+    const float alpha = (p.flags & Y3_EPI_LRELU) ? p.alpha : 1.f;   // flags folded into constants: no selects per value in the epilogue
     const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.resid ? p.resid : p.src), 0, p.resid_bytes, 0x00020000);
     const int aOH = p.OH, aOW = p.OW, dst_ld = p.dst_ld, resid_ld = p.resid_ld;
@@ -1337,8 +1345,8 @@ __global__ __launch_bounds__(512) void conv_bf16_c64_kernel(const PatchArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float x = fin[r][4 * gq + j] + eb[j];
-                    if (do_lrelu) x = x > 0.f ? x : alpha * x;
-                    if (has_scale) x = x * es[j] + ef[j];
+                    x = __builtin_fmaxf(x, alpha * x);       // leaky-relu for 0 <= alpha <= 1 (the host checks); alpha = 1 without one
+                    x = x * es[j] + ef[j];                   // scale 1, shift 0 without a folded BatchNorm
                     v[4 * gq + j] = x;
                 }
             }
@@ -1597,7 +1605,8 @@ static int conv2d_fwd_bf16_impl(const y3_tensor* src, const void* wt_t_bf16, con
     }
     // the patch kernel for the 32 -> 64 3x3 layers (conv_bf16_c32_kernel)
     static const int patch_on = dev_int("Y3_BF16_PATCH", 1);   // 0 = off (A/B against conv_bf16_kernel<128, 64>)
-    if (patch_on && ksize == 3 && p.C == 32 && p.Nout == 64 && !dst_is_f32 && p.vec_ok && ((uintptr_t)wt_t_bf16 & 15) == 0 &&
+    const bool patch_epi_ok = !(flags & Y3_EPI_LRELU) || (alpha >= 0.f && alpha <= 1.f);   // their leaky-relu is max(x, alpha x)
+    if (patch_on && patch_epi_ok && ksize == 3 && p.C == 32 && p.Nout == 64 && !dst_is_f32 && p.vec_ok && ((uintptr_t)wt_t_bf16 & 15) == 0 &&
         (!bias || ((uintptr_t)bias & 3) == 0) && src->h < 0x4000 && src->w < 0x4000) {
         PatchArgs q = {};
         q.src = (const u16*)src->ptr;
@@ -1640,7 +1649,7 @@ static int conv2d_fwd_bf16_impl(const y3_tensor* src, const void* wt_t_bf16, con
         Y3_CHECK_LAUNCH("conv_bf16_c32");
         return Y3_OK;
     }
-    if (patch_on && ksize == 3 && p.C == 64 && p.Nout == 128 && !dst_is_f32 && p.vec_ok && ((uintptr_t)wt_t_bf16 & 15) == 0 &&
+    if (patch_on && patch_epi_ok && ksize == 3 && p.C == 64 && p.Nout == 128 && !dst_is_f32 && p.vec_ok && ((uintptr_t)wt_t_bf16 & 15) == 0 &&
         src->h < 0x4000 && src->w < 0x4000) {
         PatchArgs q = {};
         q.src = (const u16*)src->ptr;
