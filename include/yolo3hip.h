@@ -258,7 +258,12 @@ int y3_upsample_sum2x_bwd(const y3_tensor* dout, const y3_tensor* din, y3_stream
  * Which kernel runs is the library's choice and does not change the contract: the 3x3 layers 32 -> 64 and 64 -> 128 with bf16
  * output and 16-byte aligned rows (the 608^2 -> 152^2 stages of the tiled path) take HBM-bound patch kernels (input patch once
  * through LDS, weights in registers), Cin % 64 == 0 with Cout >= 256 and >= 96 tiles of 256 x 256 the ping-pong kernel, the rest
- * the LDS-DMA ring kernel.  All of them accumulate in fp32 and round once. */
+ * the LDS-DMA ring kernel.  All of them accumulate in fp32 and round once.
+ * Y3_BF16_NO_PATCH in `flags` keeps a launch off the patch kernels: they win where a layer streams from HBM (hundreds of MB:
+ * batches of 25+ tiles of 608^2) and lose 2 % of a whole forward at batch 8, where the next layer finds the ring kernel's
+ * output in its own XCD's L2 (the patch kernels write strip-wise).  The caller knows its batch: yolo3/model.py sets the flag for
+ * layers that move less than 300 MB. */
+#define Y3_BF16_NO_PATCH 8u
 int y3_conv2d_fwd_bf16(const y3_tensor* src, const void* wt_t_bf16, const float* bias, int ksize, int stride,
                        const y3_tensor* dst, int dst_is_f32, unsigned flags, float alpha,
                        const float* scale, const float* shift, const y3_tensor* resid, y3_stream_t stream);

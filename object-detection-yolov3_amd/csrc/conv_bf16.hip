@@ -1605,7 +1605,7 @@ static int conv2d_fwd_bf16_impl(const y3_tensor* src, const void* wt_t_bf16, con
     }
     // the patch kernel for the 32 -> 64 3x3 layers (conv_bf16_c32_kernel)
     static const int patch_on = dev_int("Y3_BF16_PATCH", 1);   // 0 = off (A/B against conv_bf16_kernel<128, 64>)
-    const bool patch_epi_ok = !(flags & Y3_EPI_LRELU) || (alpha >= 0.f && alpha <= 1.f);   // their leaky-relu is max(x, alpha x)
+    const bool patch_epi_ok = !(flags & Y3_BF16_NO_PATCH) && (!(flags & Y3_EPI_LRELU) || (alpha >= 0.f && alpha <= 1.f));   // their leaky-relu is max(x, alpha x)
     if (patch_on && patch_epi_ok && ksize == 3 && p.C == 32 && p.Nout == 64 && !dst_is_f32 && p.vec_ok && ((uintptr_t)wt_t_bf16 & 15) == 0 &&
         (!bias || ((uintptr_t)bias & 3) == 0) && src->h < 0x4000 && src->w < 0x4000) {
         PatchArgs q = {};

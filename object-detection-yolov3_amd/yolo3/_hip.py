@@ -118,6 +118,7 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 EPI_LRELU = 1
 EPI_ACCUM = 2
+BF16_NO_PATCH = 8   # Y3_BF16_NO_PATCH: keep a y3_conv2d_fwd_bf16 launch off the patch kernels (small batches, yolo3hip.h)
 CONV_X3 = 4      # Y3_CONV_X3: fp32 arithmetic as three bf16 pieces per operand (conv_x3.hip); the weight operand changes layout
 
 

@@ -19,13 +19,14 @@ import torch
 
 from . import _hip
 from . import streams
-from ._hip import lib, check, view, EPI_LRELU, EPI_ACCUM, CONV_X3
+from ._hip import lib, check, view, EPI_LRELU, EPI_ACCUM, CONV_X3, BF16_NO_PATCH
 
 BN_EPS = 1e-3          # Keras BatchNormalization defaults
 BN_MOMENTUM = 0.99
 BN_EPILOGUE_STATS = os.environ.get('Y3_BN_EPI', '1') != '0'   # BatchNorm-backward statistics from the epilogue of the data gradient that completes dy
 BN_EPILOGUE_WIDE = os.environ.get('Y3_BN_EPI_WIDE', '1') != '0'   # ... also when the consumer is a stride-2 convolution or reads a concat slice
 LRELU_ALPHA = 0.2      # tf.nn.leaky_relu default (App. C3)
+BF16_PATCH_MIN_BYTES = 300e6   # bf16 path: a 3x3 layer that moves less (input + residual + output) stays off the patch kernels
 ALIGN = 64             # arena alignment in floats (256 B)
 
 
@@ -296,7 +297,11 @@ class _Plan:
                 self.ops.append(('conv_layer', i, src, a, y, resid, (smean, srstd, coef)))
             elif bf and i > 0:
                 # (the shared conv workspace: small-M layers are split along K, y3_conv2d_fwd_bf16_workspace)
-                self._conv_call(self.fwd, y.m, sp, lib.y3_conv2d_fwd_bf16_ws, src.v, wbf(sp.w_off), ptr(sp.b_off), sp.k, sp.s, y.v, 0, EPI_LRELU,
+                # the patch kernels of the early 3x3 layers only where the layer streams from HBM (yolo3hip.h, Y3_BF16_NO_PATCH;
+                # same box, graph replay: 25 x 608^2 6.54 -> 6.25 ms with them, 8 x 608^2 2.56 -> 2.61, 8 x 416^2 1.74 -> 1.78)
+                moved = 2 * y.m * (sp.s * sp.s * sp.cin_pad + sp.cout * (2 if resid is not None else 1))
+                self._conv_call(self.fwd, y.m, sp, lib.y3_conv2d_fwd_bf16_ws, src.v, wbf(sp.w_off), ptr(sp.b_off), sp.k, sp.s, y.v, 0,
+                                EPI_LRELU | (0 if moved >= BF16_PATCH_MIN_BYTES else BF16_NO_PATCH),
                                 LRELU_ALPHA, scale, shift, resid.v if resid is not None else None,
                                 need=int(lib.y3_conv2d_fwd_bf16_workspace(y.m, sp.cin_pad, sp.k, sp.cout)))
             elif bf and sp.cin_pad == 4 and sp.cout == 32 and sp.k == 3 and sp.s == 1:

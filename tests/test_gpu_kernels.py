@@ -326,6 +326,35 @@ def test_conv_bf16_patch_kernels_are_race_free_at_tiled_shapes(hip, shape):
     assert bool(torch.isfinite(got).all()) and bool(((got - ref).abs() <= bound).all()), 'max excess %.3e' % float(((got - ref).abs() - bound).max())
 
 
+def test_conv_bf16_no_patch_flag_falls_back_to_the_ring_kernel(hip):
+    """Y3_BF16_NO_PATCH keeps a 32 -> 64 / 64 -> 128 3x3 launch off the patch kernels (yolo3/model.py sets it for layers that
+    move less than 300 MB): same operands, both kernels accumulate in fp32 and round once, so the two outputs agree to one bf16
+    ulp + accumulation order.  (For 32 -> 64 they are bit-identical: the patch kernel walks K in the ring kernel's order -- tap,
+    then 16-channel step -- on the same instruction; the 64 -> 128 kernel adds its two K halves at the end.)"""
+    from util import stream
+    for cin, cout, s in ((32, 64, 1), (64, 128, 2)):
+        n, h, w, k = 2, 64, 96, 3
+        oh, ow = -(-h // s), -(-w // s)
+        g = torch.Generator().manual_seed(31 + cin)
+        xd = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16).cuda()
+        wk = (torch.randn(k, k, cin, cout, generator=g) * 0.08).to(torch.bfloat16)
+        bd = torch.randn(cout, generator=g).cuda()
+        wf = wk.float().contiguous().cuda()
+        wt = torch.empty(k * k * cout * cin, device='cuda')
+        hip.check(hip.lib.y3_transpose_weights(wf.data_ptr(), wt.data_ptr(), k * k, cin, cout, stream()))
+        wtb = torch.empty(k * k * cout * cin, dtype=torch.bfloat16, device='cuda')
+        hip.check(hip.lib.y3_f32_to_bf16(wt.data_ptr(), wtb.data_ptr(), wt.numel(), stream()))
+        outs = []
+        for flags in (hip.EPI_LRELU, hip.EPI_LRELU | hip.BF16_NO_PATCH):
+            y = torch.full((n, oh, ow, cout), float('nan'), dtype=torch.bfloat16, device='cuda')
+            hip.check(hip.lib.y3_conv2d_fwd_bf16(hip.Tensor(xd.data_ptr(), n, h, w, cin, cin), wtb.data_ptr(), bd.data_ptr(), k, s,
+                                                 hip.Tensor(y.data_ptr(), n, oh, ow, cout, cout), 0, flags, 0.2, None, None, None, stream()))
+            outs.append(y.double())
+        a, b = outs
+        scale = float(a.abs().max())
+        assert bool(torch.isfinite(b).all()) and bool(((a - b).abs() <= a.abs() * 2.0 ** -7 + 4e-5 * scale).all())
+
+
 def test_conv_first_bf16(hip):
     """y3_conv2d_first_bf16 (direct fp32 convolution of the RGB layer, bf16 store) vs fp64: half a bf16 ulp + 1e-5 of scale."""
     from util import nhwc_buf, stream
