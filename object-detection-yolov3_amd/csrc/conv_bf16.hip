@@ -1607,7 +1607,7 @@ static int conv2d_fwd_bf16_impl(const y3_tensor* src, const void* wt_t_bf16, con
     static const int patch_on = dev_int("Y3_BF16_PATCH", 1);   // 0 = off (A/B against conv_bf16_kernel<128, 64>)
     const bool patch_epi_ok = !(flags & Y3_BF16_NO_PATCH) && (!(flags & Y3_EPI_LRELU) || (alpha >= 0.f && alpha <= 1.f));   // their leaky-relu is max(x, alpha x)
     if (patch_on && patch_epi_ok && ksize == 3 && p.C == 32 && p.Nout == 64 && !dst_is_f32 && p.vec_ok && ((uintptr_t)wt_t_bf16 & 15) == 0 &&
-        (!bias || ((uintptr_t)bias & 3) == 0) && src->h < 0x4000 && src->w < 0x4000) {
+        (!bias || ((uintptr_t)bias & 3) == 0)) {
         PatchArgs q = {};
         q.src = (const u16*)src->ptr;
         q.wt = (const u16*)wt_t_bf16;
@@ -1649,8 +1649,7 @@ static int conv2d_fwd_bf16_impl(const y3_tensor* src, const void* wt_t_bf16, con
         Y3_CHECK_LAUNCH("conv_bf16_c32");
         return Y3_OK;
     }
-    if (patch_on && patch_epi_ok && ksize == 3 && p.C == 64 && p.Nout == 128 && !dst_is_f32 && p.vec_ok && ((uintptr_t)wt_t_bf16 & 15) == 0 &&
-        src->h < 0x4000 && src->w < 0x4000) {
+    if (patch_on && patch_epi_ok && ksize == 3 && p.C == 64 && p.Nout == 128 && !dst_is_f32 && p.vec_ok && ((uintptr_t)wt_t_bf16 & 15) == 0) {
         PatchArgs q = {};
         q.src = (const u16*)src->ptr;
         q.wt = (const u16*)wt_t_bf16;
