@@ -1701,7 +1701,11 @@ static int conv2d_fwd_bf16_impl(const y3_tensor* src, const void* wt_t_bf16, con
             launch_bf16<256, 128, 4, 2, false, 64>(p, y3_cdiv(p.M, 256) * p.nbn, st);
     } else if (force == 2 || (force == 0 && t128 >= 512)) {
         p.nbn = y3_cdiv(p.Nout, 128);
-        if (p.resid)
+        // with or without a residual through the staged epilogue (16-byte stores over whole tile rows).  Round 2 preferred the direct
+        // one (2-byte stores from registers, 3 waves per SIMD) where there is nothing to load; re-measured at the batches the tiled path
+        // plans (45 x 608^2, same box): the ten 256 -> 128 1x1 launches of the 76^2 stage 60 -> 55 us, 512 -> 128 88 -> 76
+        static const int direct128 = dev_int("Y3_BF16_DIRECT128", 0);   // 1 = the direct epilogue again (A/B)
+        if (p.resid || !direct128)
             launch_bf16<128, 128, 2, 2, true>(p, y3_cdiv(p.M, 128) * p.nbn, st);
         else
             launch_bf16<128, 128, 2, 2, false>(p, y3_cdiv(p.M, 128) * p.nbn, st);
