@@ -1695,7 +1695,10 @@ static int conv2d_fwd_bf16_impl(const y3_tensor* src, const void* wt_t_bf16, con
         launch_bf16<128, 64, 4, 1>(p, y3_cdiv(p.M, 128), st);
     } else if (k64 && (force == 3 || (force == 0 && t256 >= 150 && t256 <= 300))) {
         p.nbn = y3_cdiv(p.Nout, 128);
-        if (p.resid)
+        // (staged epilogue without a residual too, as for the 128 x 128 launches below: same box 8 x 608^2 2.552 -> 2.530 ms, 8 x 416^2
+        // 1.729 -> 1.722, 25 / 45 tiles unchanged)
+        static const int direct256 = dev_int("Y3_BF16_DIRECT256", 0);   // 1 = the direct epilogue again (A/B)
+        if (p.resid || !direct256)
             launch_bf16<256, 128, 4, 2, true, 64>(p, y3_cdiv(p.M, 256) * p.nbn, st);
         else
             launch_bf16<256, 128, 4, 2, false, 64>(p, y3_cdiv(p.M, 256) * p.nbn, st);

@@ -148,6 +148,7 @@ BF16_CASES = [
     (2, 128, 128, 32, 128, 3, 1, True, False),   # 128x128 tiles
     (1, 64, 64, 64, 32, 1, 1, False, False),     # BN=32 tile
     (4, 128, 128, 32, 128, 1, 1, False, False),  # 512 tiles of 128x128 WITHOUT a residual: the staged epilogue (round 4; the direct one before)
+    (4, 100, 100, 64, 128, 1, 1, False, False),  # 157 tiles of 256x128 (K steps of 64) without a residual: staged epilogue too
     (3, 20, 20, 64, 64, 3, 1, True, False),      # BN=64 tile, ragged M
     (1, 13, 13, 512, 1024, 3, 1, True, False),   # long K
     (1, 26, 26, 768, 256, 1, 1, False, False),   # 1x1 with non-power-of-two Cin (route concat)
